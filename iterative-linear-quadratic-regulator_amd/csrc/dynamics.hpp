@@ -1,0 +1,515 @@
+// dynamics.hpp -- device-side systems, integrators and quadratic costs for gfx950.
+//
+// What the reference builds with JAX closures + autodiff in
+// python/class_files/systems/system_base.py:25-251 is written out here as plain
+// per-lane device functions templated on the scalar type: the continuous
+// dynamics f_c and its Jacobians, the four integrators (+ their exact discrete
+// Jacobians by the chain rule through the stages = what jacfwd evaluates,
+// system_base.py:203-205; implicit-function theorem for backward Euler,
+// :146-188) and the quadratic stage / terminal costs with their derivatives
+// (:212-219).  One lane evaluates one (trajectory, timestep) point; all loops
+// have compile-time bounds so every array lives in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/ilqr_hip.h"
+
+#define ILQR_DEV __device__ __forceinline__
+
+namespace ilqr {
+
+template <typename T> struct M;
+template <> struct M<float> {
+    static ILQR_DEV float sin(float x) { return sinf(x); }
+    static ILQR_DEV float cos(float x) { return cosf(x); }
+    static ILQR_DEV float sqrt(float x) { return sqrtf(x); }
+    static ILQR_DEV float abs(float x) { return fabsf(x); }
+    static ILQR_DEV void sincos(float x, float* s, float* c) { sincosf(x, s, c); }
+};
+template <> struct M<double> {
+    static ILQR_DEV double sin(double x) { return ::sin(x); }
+    static ILQR_DEV double cos(double x) { return ::cos(x); }
+    static ILQR_DEV double sqrt(double x) { return ::sqrt(x); }
+    static ILQR_DEV double abs(double x) { return fabs(x); }
+    static ILQR_DEV void sincos(double x, double* s, double* c) { ::sincos(x, s, c); }
+};
+
+// ---------------------------------------------------------------------------
+// Device parameter block (scalars of type T, built on the host in double by
+// build_device_params() in ilqr_abi.hip):
+//   [ derived system constants (NSYS) | x_target (n) | Q (n*n) | R (m*m) | Q_f (n*n)
+//     | Qs (n*n) | Rs (m*m) | Qfs (n*n) ]      Xs = 0.5*(X + X')
+// The pointer is a kernel argument indexed by compile-time constants, so the
+// compiler reads it with scalar loads (s_load) -- no VGPRs, no LDS.
+// ---------------------------------------------------------------------------
+template <int NSYS, int NX, int NU> struct ParamLayout {
+    static constexpr int SYS = 0;
+    static constexpr int XT = NSYS;
+    static constexpr int Q = XT + NX;
+    static constexpr int R = Q + NX * NX;
+    static constexpr int QF = R + NU * NU;
+    static constexpr int QS = QF + NX * NX;
+    static constexpr int RS = QS + NX * NX;
+    static constexpr int QFS = RS + NU * NU;
+    static constexpr int TOTAL = QFS + NX * NX;
+};
+
+// ---- pendulum (pendulum_sys.py:60-75): derived constants [g/l, d] ------------
+template <typename T> struct Pendulum {
+    static constexpr int NX = 2, NU = 1, NSYS = 2, ID = ILQR_SYS_PENDULUM;
+    static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
+        xd[0] = x[1];
+        xd[1] = u[0] - p[1] * x[1] - p[0] * M<T>::sin(x[0]);
+    }
+    static ILQR_DEV void fjac(const T* __restrict__ p, const T* x, const T* u, T* xd, T (*Jx)[2], T (*Ju)[1]) {
+        T s, c;
+        M<T>::sincos(x[0], &s, &c);
+        xd[0] = x[1];
+        xd[1] = u[0] - p[1] * x[1] - p[0] * s;
+        Jx[0][0] = T(0); Jx[0][1] = T(1);
+        Jx[1][0] = -p[0] * c; Jx[1][1] = -p[1];
+        Ju[0][0] = T(0); Ju[1][0] = T(1);
+    }
+};
+
+// ---- double pendulum (UA_double_pendulum_sys.py:84-208, double_pendulum_sys.py:84-206)
+// derived constants: [a = m2 l1 l2, c11 = m1 l1^2/4 + m2 l1^2 + m2 l2^2/4 + th1 + th2,
+//                     c12 = m2 l2^2/4 + th2 (= m22), gA = m2 g l2/2, gB = (m2 + m1/2) g l1, d1, d2]
+template <typename T, int NU_> struct DoublePendulum {
+    static constexpr int NX = 4, NU = NU_, NSYS = 7;
+    static constexpr int ID = (NU_ == 1) ? ILQR_SYS_UA_DOUBLE_PENDULUM : ILQR_SYS_DOUBLE_PENDULUM;
+
+    static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
+        const T a = p[0], c11 = p[1], c12 = p[2], gA = p[3], gB = p[4], d1 = p[5], d2 = p[6];
+        const T q1 = x[0], q2 = x[1], q1d = x[2], q2d = x[3];
+        T s1 = M<T>::sin(q1), s12 = M<T>::sin(q1 + q2), s2, c2;
+        M<T>::sincos(q2, &s2, &c2);
+        const T m11 = c11 + a * c2, m12 = c12 + T(0.5) * a * c2, m22 = c12;
+        const T as2 = a * s2;
+        T h1 = u[0] + T(0.5) * as2 * (T(2) * q1d * q2d + q2d * q2d) - gA * s12 - gB * s1 - d1 * q1d;
+        T h2 = -T(0.5) * as2 * q1d * q1d - gA * s12 - d2 * q2d;
+        if (NU == 2) h2 += u[NU - 1];
+        const T idet = T(1) / (m11 * m22 - m12 * m12);
+        xd[0] = q1d;
+        xd[1] = q2d;
+        xd[2] = (m22 * h1 - m12 * h2) * idet;
+        xd[3] = (m11 * h2 - m12 * h1) * idet;
+    }
+
+    // M qdd = h  =>  d qdd = M^-1 (dh - dM qdd)
+    static ILQR_DEV void fjac(const T* __restrict__ p, const T* x, const T* u, T* xd, T (*Jx)[4], T (*Ju)[NU]) {
+        const T a = p[0], c11 = p[1], c12 = p[2], gA = p[3], gB = p[4], d1 = p[5], d2 = p[6];
+        const T q1 = x[0], q2 = x[1], q1d = x[2], q2d = x[3];
+        T s1, c1, s2, c2, s12, c12q;
+        M<T>::sincos(q1, &s1, &c1);
+        M<T>::sincos(q2, &s2, &c2);
+        M<T>::sincos(q1 + q2, &s12, &c12q);
+        const T m11 = c11 + a * c2, m12 = c12 + T(0.5) * a * c2, m22 = c12;
+        const T as2 = a * s2, ac2 = a * c2;
+        const T w = T(2) * q1d * q2d + q2d * q2d;
+        T h1 = u[0] + T(0.5) * as2 * w - gA * s12 - gB * s1 - d1 * q1d;
+        T h2 = -T(0.5) * as2 * q1d * q1d - gA * s12 - d2 * q2d;
+        if (NU == 2) h2 += u[NU - 1];
+        const T idet = T(1) / (m11 * m22 - m12 * m12);
+        const T i11 = m22 * idet, i12 = -m12 * idet, i22 = m11 * idet;
+        const T qdd1 = i11 * h1 + i12 * h2, qdd2 = i12 * h1 + i22 * h2;
+        xd[0] = q1d; xd[1] = q2d; xd[2] = qdd1; xd[3] = qdd2;
+        // dh/dz, z = q1, q2, q1d, q2d
+        T dh1[4], dh2[4];
+        dh1[0] = -gA * c12q - gB * c1;
+        dh2[0] = -gA * c12q;
+        // dM/dq2 = [[-a s2, -a s2/2], [-a s2/2, 0]]
+        dh1[1] = T(0.5) * ac2 * w - gA * c12q + as2 * qdd1 + T(0.5) * as2 * qdd2;
+        dh2[1] = -T(0.5) * ac2 * q1d * q1d - gA * c12q + T(0.5) * as2 * qdd1;
+        dh1[2] = as2 * q2d - d1;
+        dh2[2] = -as2 * q1d;
+        dh1[3] = as2 * (q1d + q2d);
+        dh2[3] = -d2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Jx[0][j] = T(j == 2);
+            Jx[1][j] = T(j == 3);
+            Jx[2][j] = i11 * dh1[j] + i12 * dh2[j];
+            Jx[3][j] = i12 * dh1[j] + i22 * dh2[j];
+        }
+        Ju[0][0] = T(0); Ju[1][0] = T(0); Ju[2][0] = i11; Ju[3][0] = i12;
+        if (NU == 2) {
+            Ju[0][NU - 1] = T(0); Ju[1][NU - 1] = T(0); Ju[2][NU - 1] = i12; Ju[3][NU - 1] = i22;
+        }
+    }
+};
+
+// ---- linear system x_dot = A x + B u (matlab/CLASSES/Linear_iLQR_CLASS.m:56-60)
+// derived constants: A (n*n), B (n*m) row-major
+template <typename T, int NX_, int NU_> struct Linear {
+    static constexpr int NX = NX_, NU = NU_, NSYS = NX_ * NX_ + NX_ * NU_, ID = ILQR_SYS_LINEAR;
+    static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) acc += p[i * NX + j] * x[j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) acc += p[NX * NX + i * NU + j] * u[j];
+            xd[i] = acc;
+        }
+    }
+    static ILQR_DEV void fjac(const T* __restrict__ p, const T* x, const T* u, T* xd, T (*Jx)[NX_], T (*Ju)[NU_]) {
+        f(p, x, u, xd);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Jx[i][j] = p[i * NX + j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Ju[i][j] = p[NX * NX + i * NU + j];
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// small dense helpers (compile-time sizes, static indexing only)
+// ---------------------------------------------------------------------------
+// In-place LU with partial pivoting realised as predicated row swaps, so no
+// dynamically indexed register arrays (= no scratch).  Solves A X = RHS for NR
+// right-hand sides held as columns of rhs[N][NR].
+template <typename T, int N, int NR>
+ILQR_DEV void lu_solve_inplace(T (*A)[N], T (*rhs)[NR]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        // pivot search
+        T best = M<T>::abs(A[k][k]);
+        int piv = k;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            T v = M<T>::abs(A[i][k]);
+            if (v > best) { best = v; piv = i; }
+        }
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const bool sw = (piv == i);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                T a = A[k][j], b = A[i][j];
+                A[k][j] = sw ? b : a;
+                A[i][j] = sw ? a : b;
+            }
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+                T a = rhs[k][j], b = rhs[i][j];
+                rhs[k][j] = sw ? b : a;
+                rhs[i][j] = sw ? a : b;
+            }
+        }
+        const T inv = T(1) / A[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const T l = A[i][k] * inv;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) A[i][j] -= l * A[k][j];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) rhs[i][j] -= l * rhs[k][j];
+        }
+    }
+    // back substitution
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        const T inv = T(1) / A[k][k];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            T acc = rhs[k][j];
+#pragma unroll
+            for (int i = k + 1; i < N; ++i) acc -= A[k][i] * rhs[i][j];
+            rhs[k][j] = acc * inv;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// integrators (system_base.py:50-140) and their discrete Jacobians
+// ---------------------------------------------------------------------------
+template <typename T, typename Dyn> struct Stepper {
+    static constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    // big linear systems only get the closed-form integrators (register budget)
+    static constexpr bool SMALL = (NX <= 4);
+
+    // backward Euler quasi-Newton (system_base.py:88-140): explicit-Euler guess, one
+    // Jacobian I - dt*J_x at the guess reused, stop at ||F||_2 <= 1e-5 or 20 iterations.
+    static ILQR_DEV void backward_euler(const T* __restrict__ p, T dt, const T* x, const T* u, T* xn) {
+        T k[NX], Jx[NX][NX], Ju[NX][NU];
+        Dyn::f(p, x, u, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = x[i] + dt * k[i];
+        Dyn::fjac(p, xn, u, k, Jx, Ju);
+        T J[NX][NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) J[i][j] = T(i == j) - dt * Jx[i][j];
+        T F[NX], nrm2 = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { F[i] = xn[i] - x[i] - dt * k[i]; nrm2 += F[i] * F[i]; }
+        int it = 0;
+        while (M<T>::sqrt(nrm2) > T(1e-5) && it < 20) {
+            T Jc[NX][NX], r[NX][1];
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                r[i][0] = -F[i];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) Jc[i][j] = J[i][j];
+            }
+            lu_solve_inplace<T, NX, 1>(Jc, r);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xn[i] += r[i][0];
+            Dyn::f(p, xn, u, k);
+            nrm2 = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) { F[i] = xn[i] - x[i] - dt * k[i]; nrm2 += F[i] * F[i]; }
+            ++it;
+        }
+    }
+
+    static ILQR_DEV void step(int integ, const T* __restrict__ p, T dt, const T* x, const T* u, T* xn) {
+        T k1[NX];
+        if (integ == ILQR_INT_DISCRETE) { Dyn::f(p, x, u, xn); return; }
+        if (integ == ILQR_INT_EULER || !SMALL) {
+            Dyn::f(p, x, u, k1);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xn[i] = x[i] + k1[i] * dt;
+            return;
+        }
+        if constexpr (SMALL) {
+            if (integ == ILQR_INT_MIDPOINT) {
+                T xm[NX], k2[NX];
+                Dyn::f(p, x, u, k1);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xm[i] = x[i] + (dt / T(2)) * k1[i];
+                Dyn::f(p, xm, u, k2);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xn[i] = x[i] + dt * k2[i];
+                return;
+            }
+            if (integ == ILQR_INT_RK4) {
+                T xs[NX], k2[NX], k3[NX], k4[NX];
+                Dyn::f(p, x, u, k1);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[i] = x[i] + dt / T(2) * k1[i];
+                Dyn::f(p, xs, u, k2);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[i] = x[i] + dt / T(2) * k2[i];
+                Dyn::f(p, xs, u, k3);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) xs[i] = x[i] + dt * k3[i];
+                Dyn::f(p, xs, u, k4);
+#pragma unroll
+                for (int i = 0; i < NX; ++i)
+                    xn[i] = x[i] + (dt / T(6)) * (k1[i] + T(2) * k2[i] + T(2) * k3[i] + k4[i]);
+                return;
+            }
+            backward_euler(p, dt, x, u, xn);
+        }
+    }
+
+    // C = A*B helpers on register tiles
+    template <int R, int K, int C>
+    static ILQR_DEV void matmul(const T (*A)[K], const T (*B)[C], T (*out)[C]) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < C; ++j) {
+                T acc = T(0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc += A[i][k] * B[k][j];
+                out[i][j] = acc;
+            }
+    }
+
+    // one explicit stage of the chain rule: given the stage point xs = x + c*k_prev with
+    // d xs/dx = I + c*Kx_prev, d xs/du = c*Ku_prev, evaluate k = f_c(xs, u) and
+    // Kx = J_x(xs) (I + c Kx_prev), Ku = J_x(xs) (c Ku_prev) + J_u(xs).
+    static ILQR_DEV void stage(const T* __restrict__ p, const T* x, const T* u, T c, const T* kprev,
+                               const T (*Kxp)[NX], const T (*Kup)[NU], T* k, T (*Kx)[NX], T (*Ku)[NU]) {
+        T xs[NX], Jx[NX][NX], Ju[NX][NU], Dx[NX][NX], Du[NX][NU];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            xs[i] = x[i] + c * kprev[i];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Dx[i][j] = T(i == j) + c * Kxp[i][j];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Du[i][j] = c * Kup[i][j];
+        }
+        Dyn::fjac(p, xs, u, k, Jx, Ju);
+        matmul<NX, NX, NX>(Jx, Dx, Kx);
+        matmul<NX, NX, NU>(Jx, Du, Ku);
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+            for (int j = 0; j < NU; ++j) Ku[i][j] += Ju[i][j];
+    }
+
+    // f, f_x, f_u of the discrete map at (x, u)
+    static ILQR_DEV void step_jac(int integ, const T* __restrict__ p, T dt, const T* x, const T* u, T* xn,
+                                  T (*fx)[NX], T (*fu)[NU]) {
+        T k1[NX];
+        if (integ == ILQR_INT_DISCRETE) { Dyn::fjac(p, x, u, xn, fx, fu); return; }
+        if (integ == ILQR_INT_EULER || !SMALL) {
+            Dyn::fjac(p, x, u, k1, fx, fu);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                xn[i] = x[i] + k1[i] * dt;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) fx[i][j] = T(i == j) + dt * fx[i][j];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) fu[i][j] = dt * fu[i][j];
+            }
+            return;
+        }
+        if constexpr (SMALL) {
+            T K1x[NX][NX], K1u[NX][NU];
+            if (integ == ILQR_INT_MIDPOINT) {
+                T k2[NX], K2x[NX][NX], K2u[NX][NU];
+                Dyn::fjac(p, x, u, k1, K1x, K1u);
+                stage(p, x, u, dt / T(2), k1, K1x, K1u, k2, K2x, K2u);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    xn[i] = x[i] + dt * k2[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) fx[i][j] = T(i == j) + dt * K2x[i][j];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) fu[i][j] = dt * K2u[i][j];
+                }
+                return;
+            }
+            if (integ == ILQR_INT_RK4) {
+                T k[NX], Kx[NX][NX], Ku[NX][NU], kn[NX], Knx[NX][NX], Knu[NX][NU];
+                T sk[NX], sx[NX][NX], su[NX][NU];
+                Dyn::fjac(p, x, u, k, Kx, Ku);
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    sk[i] = k[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) sx[i][j] = Kx[i][j];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) su[i][j] = Ku[i][j];
+                }
+                const T cs[3] = {dt / T(2), dt / T(2), dt};
+                const T ws[3] = {T(2), T(2), T(1)};
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    stage(p, x, u, cs[s], k, Kx, Ku, kn, Knx, Knu);
+#pragma unroll
+                    for (int i = 0; i < NX; ++i) {
+                        k[i] = kn[i];
+                        sk[i] += ws[s] * kn[i];
+#pragma unroll
+                        for (int j = 0; j < NX; ++j) { Kx[i][j] = Knx[i][j]; sx[i][j] += ws[s] * Knx[i][j]; }
+#pragma unroll
+                        for (int j = 0; j < NU; ++j) { Ku[i][j] = Knu[i][j]; su[i][j] += ws[s] * Knu[i][j]; }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    xn[i] = x[i] + (dt / T(6)) * sk[i];
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) fx[i][j] = T(i == j) + (dt / T(6)) * sx[i][j];
+#pragma unroll
+                    for (int j = 0; j < NU; ++j) fu[i][j] = (dt / T(6)) * su[i][j];
+                }
+                return;
+            }
+            // backward Euler: implicit-function theorem at the converged point
+            // (system_base.py:146-188): f_x = (I - dt J_x)^-1, f_u = (I - dt J_x)^-1 dt J_u
+            backward_euler(p, dt, x, u, xn);
+            T Jx[NX][NX], Ju[NX][NU], J[NX][NX], rhs[NX][NX + NU];
+            Dyn::fjac(p, xn, u, k1, Jx, Ju);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { J[i][j] = T(i == j) - dt * Jx[i][j]; rhs[i][j] = T(i == j); }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) rhs[i][NX + j] = dt * Ju[i][j];
+            }
+            lu_solve_inplace<T, NX, NX + NU>(J, rhs);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) fx[i][j] = rhs[i][j];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) fu[i][j] = rhs[i][NX + j];
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// quadratic costs (pendulum_sys.py:77-98, UA_double_pendulum_sys.py:114-136)
+// ---------------------------------------------------------------------------
+template <typename T, typename Dyn> struct Cost {
+    static constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    using L = ParamLayout<Dyn::NSYS, NX, NU>;
+
+    // l(x,u) = (0.5 dx'Q dx + 0.5 u'R u) * dt
+    static ILQR_DEV T stage(const T* __restrict__ p, T dt, const T* x, const T* u) {
+        T dx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - p[L::XT + i];
+        T cx = T(0), cu = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T r = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r += p[L::Q + i * NX + j] * dx[j];
+            cx += dx[i] * r;
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            T r = T(0);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) r += p[L::R + i * NU + j] * u[j];
+            cu += u[i] * r;
+        }
+        return (T(0.5) * cx + T(0.5) * cu) * dt;
+    }
+    // l_f(x) = 0.5 dx'Q_f dx   (not scaled by dt)
+    static ILQR_DEV T terminal(const T* __restrict__ p, const T* x) {
+        T dx[NX], c = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - p[L::XT + i];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T r = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r += p[L::QF + i * NX + j] * dx[j];
+            c += dx[i] * r;
+        }
+        return T(0.5) * c;
+    }
+    static ILQR_DEV void l_x(const T* __restrict__ p, T dt, const T* x, T* out) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T r = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r += p[L::QS + i * NX + j] * (x[j] - p[L::XT + j]);
+            out[i] = r * dt;
+        }
+    }
+    static ILQR_DEV void l_u(const T* __restrict__ p, T dt, const T* u, T* out) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            T r = T(0);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) r += p[L::RS + i * NU + j] * u[j];
+            out[i] = r * dt;
+        }
+    }
+    static ILQR_DEV void l_f_x(const T* __restrict__ p, const T* x, T* out) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T r = T(0);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) r += p[L::QFS + i * NX + j] * (x[j] - p[L::XT + j]);
+            out[i] = r;
+        }
+    }
+};
+
+}  // namespace ilqr

@@ -1,0 +1,649 @@
+// kernels.hpp -- HIP kernels of the batched iLQR hot path (gfx950 / CDNA4).
+//
+// HBM data layout ("batch innermost", scalar type T):
+//   X    [n_slots][N+1][n_x][B]      U    [n_slots][N][n_u][B]
+//   K    [N][n_u][n_x][B]            kff  [N][n_u][B]           (U_ff of the reference)
+//   lin  [N][E][B]   E = 2n^2+2nm+n+m+m^2, per step f_x f_u l_x l_u l_xx l_ux l_uu
+//   term [n + n^2][B]                (l_f_x, l_f_xx)
+//   costs [n_alpha][B]   cost, cost_prev, alpha_taken [B]   status, iters, accepted, cur_slot [B]
+// A trajectory b is a column of every tensor, so 64 consecutive trajectories are one
+// 256-B (f32) / 512-B (f64) coalesced row per wave-instruction in every kernel.
+//
+// "Slots": the current trajectory of b lives in slot cur_slot[b]; candidate a of a
+// line-search pass is rolled out into slot (cur_slot[b] + 1 + a) % n_slots, and accepting
+// a candidate is just cur_slot[b] <- that slot: no trajectory is ever copied.
+#pragma once
+#include "dynamics.hpp"
+
+namespace ilqr {
+
+constexpr int kMaxAlpha = 16;
+constexpr int kCounterRing = 64;
+
+template <typename T> struct KArgs {
+    int B, N, n_slots, integ, maxiter, flags;
+    int n_pass;      // alphas in this pass
+    int last_pass;   // select: this is the last pass of the iteration
+    int init_mode;   // select: unconditional accept of candidate 0 (initial rollout)
+    int counter_idx; // select: which ring counter receives the number of still-active trajectories
+    T dt, tol, mu;
+    T alphas[kMaxAlpha];
+    T* X; T* U; int* cur_slot;
+    T* K; T* kff; T* lin; T* term; T* x0;
+    T* costs; T* cost; T* cost_prev; T* alpha_taken;
+    int* status; int* iters; int* accepted; int* counters;
+    const T* params;
+};
+
+ILQR_DEV bool traj_active(int status) { return (status & 0xff) == ILQR_TRAJ_ACTIVE; }
+
+// ---------------------------------------------------------------------------
+// linearize: one lane per (b, t) point, t in [0, N]; t == N is the terminal
+// expansion.  Replaces iLQR._get_all_derivatives_for_backward_pass
+// (iLQR_class.py:318-331) + l_f_x / l_f_xx (:136-138), hoisted out of the
+// sequential scan because it does not depend on the carry.
+// ---------------------------------------------------------------------------
+template <typename T, typename Dyn>
+__global__ void __launch_bounds__(256) linearize_kernel(KArgs<T> a) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+    using PL = ParamLayout<Dyn::NSYS, NX, NU>;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t B = a.B;
+    const int t = (int)(idx / B);
+    const int b = (int)(idx % B);
+    if (t > a.N) return;
+    if (!traj_active(a.status[b])) return;
+    const int slot = a.cur_slot[b];
+    const T* __restrict__ p = a.params;
+    T x[NX], u[NU];
+    const T* Xp = a.X + (((size_t)slot * (a.N + 1) + t) * NX) * B + b;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = Xp[(size_t)i * B];
+    if (t == a.N) {
+        T g[NX];
+        Cost<T, Dyn>::l_f_x(p, x, g);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a.term[(size_t)i * B + b] = g[i];
+#pragma unroll
+        for (int i = 0; i < NX * NX; ++i) a.term[(size_t)(NX + i) * B + b] = p[PL::QFS + i];
+        return;
+    }
+    const T* Up = a.U + (((size_t)slot * a.N + t) * NU) * B + b;
+#pragma unroll
+    for (int i = 0; i < NU; ++i) u[i] = Up[(size_t)i * B];
+    T xn[NX], fx[NX][NX], fu[NX][NU];
+    Stepper<T, Dyn>::step_jac(a.integ, p, a.dt, x, u, xn, fx, fu);
+    T* out = a.lin + ((size_t)t * E) * B + b;
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) out[(size_t)(e++) * B] = fx[i][j];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) out[(size_t)(e++) * B] = fu[i][j];
+    T g[NX], gu[NU];
+    Cost<T, Dyn>::l_x(p, a.dt, x, g);
+    Cost<T, Dyn>::l_u(p, a.dt, u, gu);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) out[(size_t)(e++) * B] = g[i];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) out[(size_t)(e++) * B] = gu[i];
+#pragma unroll
+    for (int i = 0; i < NX * NX; ++i) out[(size_t)(e++) * B] = p[PL::QS + i] * a.dt;
+#pragma unroll
+    for (int i = 0; i < NU * NX; ++i) out[(size_t)(e++) * B] = T(0);
+#pragma unroll
+    for (int i = 0; i < NU * NU; ++i) out[(size_t)(e++) * B] = p[PL::RS + i] * a.dt;
+}
+
+// ---------------------------------------------------------------------------
+// Gain solve: [K | k] = -Quu^-1 [Qux | Qu].  Cholesky first (north_star); if Quu
+// is not positive definite fall back to LU with partial pivoting, which is what
+// the reference's jnp.linalg.solve does unconditionally (iLQR_class.py:109-110).
+// Returns false when the fallback was taken.
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NU>
+ILQR_DEV bool gain_solve(const T (*Quu)[NU], const T (*Qux)[NX], const T* Qu, T (*K)[NX], T* k) {
+    if constexpr (NU == 1) {
+        const T inv = T(1) / Quu[0][0];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) K[0][j] = -(Qux[0][j] * inv);
+        k[0] = -(Qu[0] * inv);
+        return Quu[0][0] > T(0);
+    } else {
+        T Lc[NU][NU];
+        bool pd = true;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            T d = Quu[j][j];
+#pragma unroll
+            for (int s = 0; s < j; ++s) d -= Lc[j][s] * Lc[j][s];
+            pd = pd && (d > T(0));
+            const T ljj = M<T>::sqrt(d);
+            Lc[j][j] = ljj;
+            const T inv = T(1) / ljj;
+#pragma unroll
+            for (int i = j + 1; i < NU; ++i) {
+                // lower triangle of Quu (the reference's Quu is symmetric up to rounding)
+                T v = Quu[i][j];
+#pragma unroll
+                for (int s = 0; s < j; ++s) v -= Lc[i][s] * Lc[j][s];
+                Lc[i][j] = v * inv;
+            }
+        }
+        T rhs[NU][NX + 1];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) rhs[i][j] = Qux[i][j];
+            rhs[i][NX] = Qu[i];
+        }
+        if (pd) {
+            // L y = rhs ; L' z = y
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const T inv = T(1) / Lc[i][i];
+#pragma unroll
+                for (int c = 0; c <= NX; ++c) {
+                    T v = rhs[i][c];
+#pragma unroll
+                    for (int s = 0; s < i; ++s) v -= Lc[i][s] * rhs[s][c];
+                    rhs[i][c] = v * inv;
+                }
+            }
+#pragma unroll
+            for (int i = NU - 1; i >= 0; --i) {
+                const T inv = T(1) / Lc[i][i];
+#pragma unroll
+                for (int c = 0; c <= NX; ++c) {
+                    T v = rhs[i][c];
+#pragma unroll
+                    for (int s = i + 1; s < NU; ++s) v -= Lc[s][i] * rhs[s][c];
+                    rhs[i][c] = v * inv;
+                }
+            }
+        } else {
+            T Ac[NU][NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) Ac[i][j] = Quu[i][j];
+            lu_solve_inplace<T, NU, NX + 1>(Ac, rhs);
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) K[i][j] = -rhs[i][j];
+            k[i] = -rhs[i][NX];
+        }
+        return pd;
+    }
+}
+
+// One Riccati step on register tiles (iLQR_class.py:100-114).  tile = the E scalars
+// of one (b, t) in ILQR_LIN order.
+template <typename T, int NX, int NU>
+ILQR_DEV bool riccati_step(const T* tile, T mu, T* Vx, T (*Vxx)[NX], T (*K)[NX], T* k) {
+    constexpr int oFX = 0, oFU = NX * NX, oLX = oFU + NX * NU, oLU = oLX + NX, oLXX = oLU + NU,
+                  oLUX = oLXX + NX * NX, oLUU = oLUX + NU * NX;
+    T Qx[NX], Qu[NU], P[NX][NX], Pu[NU][NX], Qxx[NX][NX], Qux[NU][NX], Quu[NU][NU];
+    // Q_x = l_x + f_x' V_x ; Q_u = l_u + f_u' V_x
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc += tile[oFX + i * NX + j] * Vx[i];
+        Qx[j] = tile[oLX + j] + acc;
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc += tile[oFU + i * NU + j] * Vx[i];
+        Qu[j] = tile[oLU + j] + acc;
+    }
+    // P = f_x' V_xx ; Pu = f_u' V_xx   (left-associated like `f_x.T @ V_xx @ f_x`)
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += tile[oFX + s * NX + i] * Vxx[s][j];
+            P[i][j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += tile[oFU + s * NU + i] * Vxx[s][j];
+            Pu[i][j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += P[i][s] * tile[oFX + s * NX + j];
+            Qxx[i][j] = tile[oLXX + i * NX + j] + acc;
+        }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += Pu[i][s] * tile[oFX + s * NX + j];
+            Qux[i][j] = tile[oLUX + i * NX + j] + acc;
+        }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += Pu[i][s] * tile[oFU + s * NU + j];
+            Quu[i][j] = tile[oLUU + i * NU + j] + acc;
+        }
+    }
+    T Qr[NU][NU];
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) Qr[i][j] = Quu[i][j] + ((i == j) ? mu : T(0));
+    const bool pd = gain_solve<T, NX, NU>(Qr, Qux, Qu, K, k);
+    if (mu == T(0)) {
+        // short form (iLQR_class.py:113-114): V_x = Q_x + K'Q_u ; V_xx = Q_xx + Q_ux' K
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NU; ++s) acc += K[s][i] * Qu[s];
+            Vx[i] = Qx[i] + acc;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                T acc2 = T(0);
+#pragma unroll
+                for (int s = 0; s < NU; ++s) acc2 += Qux[s][i] * K[s][j];
+                Vxx[i][j] = Qxx[i][j] + acc2;
+            }
+        }
+    } else {
+        // full update, exact for a regularised gain:
+        // V_x = Q_x + K'Quu k + K'Q_u + Q_ux'k ; V_xx = Q_xx + K'Quu K + K'Q_ux + Q_ux'K
+        T QK[NU][NX], Qk[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NU; ++s) acc += Quu[i][s] * k[s];
+            Qk[i] = acc;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                T acc2 = T(0);
+#pragma unroll
+                for (int s = 0; s < NU; ++s) acc2 += Quu[i][s] * K[s][j];
+                QK[i][j] = acc2;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            T acc = T(0);
+#pragma unroll
+            for (int s = 0; s < NU; ++s) acc += K[s][i] * (Qk[s] + Qu[s]) + Qux[s][i] * k[s];
+            Vx[i] = Qx[i] + acc;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                T acc2 = T(0);
+#pragma unroll
+                for (int s = 0; s < NU; ++s)
+                    acc2 += K[s][i] * (QK[s][j] + Qux[s][j]) + Qux[s][i] * K[s][j];
+                Vxx[i][j] = Qxx[i][j] + acc2;
+            }
+        }
+    }
+    return pd;
+}
+
+// ---------------------------------------------------------------------------
+// backward sweep, generic form: one lane per trajectory, reverse loop over t with
+// the next tile prefetched into registers while the current step computes.
+// Replaces iLQR._backward_pass_scan (iLQR_class.py:122-161).
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NU>
+__global__ void __launch_bounds__(64) backward_lane_kernel(KArgs<T> a) {
+    constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const int st = a.status[b];
+    if (!traj_active(st)) return;
+    const size_t B = a.B;
+    T Vx[NX], Vxx[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Vx[i] = a.term[(size_t)i * B + b];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Vxx[i][j] = a.term[(size_t)(NX + i * NX + j) * B + b];
+    T cur[E], nxt[E];
+    {
+        const T* src = a.lin + ((size_t)(a.N - 1) * E) * B + b;
+#pragma unroll
+        for (int e = 0; e < E; ++e) cur[e] = src[(size_t)e * B];
+    }
+    bool all_pd = true;
+    for (int t = a.N - 1; t >= 0; --t) {
+        if (t > 0) {
+            const T* src = a.lin + ((size_t)(t - 1) * E) * B + b;
+#pragma unroll
+            for (int e = 0; e < E; ++e) nxt[e] = src[(size_t)e * B];
+        }
+        T K[NU][NX], k[NU];
+        all_pd = riccati_step<T, NX, NU>(cur, a.mu, Vx, Vxx, K, k) && all_pd;
+        T* Kp = a.K + ((size_t)t * NU * NX) * B + b;
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+            for (int j = 0; j < NX; ++j) Kp[(size_t)(i * NX + j) * B] = K[i][j];
+        T* kp = a.kff + ((size_t)t * NU) * B + b;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) kp[(size_t)i * B] = k[i];
+#pragma unroll
+        for (int e = 0; e < E; ++e) cur[e] = nxt[e];
+    }
+    if (!all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
+}
+
+// ---------------------------------------------------------------------------
+// forward rollout: one lane per (trajectory, alpha) candidate; blockIdx.y = alpha
+// index.  Replaces iLQR._forward_pass_scan (iLQR_class.py:193-247), all trial
+// alphas of the backtracking loop (:279-302) at once.
+// ---------------------------------------------------------------------------
+template <typename T, typename Dyn>
+__global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ai = blockIdx.y;
+    if (b >= a.B) return;
+    if (!traj_active(a.status[b])) return;
+    if (a.accepted[b]) return;  // an earlier pass of this iteration already found its alpha
+    const size_t B = a.B;
+    const int N = a.N;
+    const int slot = a.cur_slot[b];
+    const int cslot = (slot + 1 + ai) % a.n_slots;
+    const T alpha = a.alphas[ai];
+    const T* __restrict__ p = a.params;
+    T x[NX], u[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = a.x0[(size_t)i * B + b];
+    T cost = T(0);
+    const T* Xo = a.X + ((size_t)slot * (N + 1) * NX) * B + b;
+    const T* Uo = a.U + ((size_t)slot * N * NU) * B + b;
+    T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + b;
+    T* Uc = a.U + ((size_t)cslot * N * NU) * B + b;
+    for (int t = 0; t < N; ++t) {
+        T dx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - Xo[((size_t)t * NX + i) * B];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            T fb = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) fb += a.K[((size_t)t * NU * NX + j * NX + i) * B + b] * dx[i];
+            // u = u_old + alpha * k + K (x - x_old)   (iLQR_class.py:181-182)
+            u[j] = Uo[((size_t)t * NU + j) * B] + alpha * a.kff[((size_t)t * NU + j) * B + b] + fb;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xc[((size_t)t * NX + i) * B] = x[i];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) Uc[((size_t)t * NU + j) * B] = u[j];
+        cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
+        T xn[NX];
+        Stepper<T, Dyn>::step(a.integ, p, a.dt, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
+    cost += Cost<T, Dyn>::terminal(p, x);
+    a.costs[(size_t)ai * B + b] = cost;
+}
+
+// ---------------------------------------------------------------------------
+// select: backtracking acceptance "first alpha with cost_new <= cost"
+// (iLQR_class.py:289-297) over the candidates of one pass, and, on the last pass
+// of an iteration, the loop bookkeeping of optimize_trajectory (:267-271, :304-311).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) select_kernel(KArgs<T> a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    bool still_active = false;
+    if (b < a.B) {
+        const size_t B = a.B;
+        if (a.init_mode) {
+            // head of optimize_trajectory: X, U, cost <- forward_pass(alpha = 0)  (:257-259)
+            const T c = a.costs[b];
+            a.cur_slot[b] = (a.cur_slot[b] + 1) % a.n_slots;
+            a.cost[b] = c;
+            a.cost_prev[b] = c;
+            a.alpha_taken[b] = T(0);
+            a.status[b] = ILQR_TRAJ_ACTIVE;
+            a.iters[b] = 0;
+            a.accepted[b] = 0;
+            still_active = true;
+        } else {
+            int st = a.status[b];
+            if (traj_active(st)) {
+                int acc = a.accepted[b];
+                const T c0 = a.cost[b];
+                if (!acc) {
+                    for (int ai = 0; ai < a.n_pass; ++ai) {
+                        const T c = a.costs[(size_t)ai * B + b];
+                        if (c <= c0) {  // NaN compares false, like the reference
+                            a.cur_slot[b] = (a.cur_slot[b] + 1 + ai) % a.n_slots;
+                            a.cost_prev[b] = c0;
+                            a.cost[b] = c;
+                            a.alpha_taken[b] = a.alphas[ai];
+                            acc = 1;
+                            break;
+                        }
+                    }
+                }
+                if (a.last_pass) {
+                    const int it = a.iters[b] + 1;
+                    a.iters[b] = it;
+                    a.accepted[b] = 0;
+                    if (!(a.flags & ILQR_FLAG_KEEP_ITERATING)) {
+                        if (!acc) {
+                            st = (st & ~0xff) | ILQR_TRAJ_LINESEARCH_FAILED;
+                        } else if (it >= a.maxiter) {
+                            st = (st & ~0xff) | ILQR_TRAJ_MAXITER;
+                        } else {
+                            const T d = M<T>::abs(a.cost[b] - a.cost_prev[b]);
+                            if (d <= a.tol) st = (st & ~0xff) | ILQR_TRAJ_CONVERGED;
+                        }
+                        a.status[b] = st;
+                    }
+                    if (!acc) a.alpha_taken[b] = T(0);
+                } else {
+                    a.accepted[b] = acc;
+                }
+                still_active = traj_active(st);
+            }
+        }
+    }
+    if (a.last_pass || a.init_mode) {
+        const unsigned long long m = __ballot(still_active);
+        if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counters[a.counter_idx], (int)__popcll(m));
+    }
+}
+
+// ---------------------------------------------------------------------------
+// eval_points: the 12 System callables (system_base.py:223-251) at arbitrary
+// points, dense row-major outputs; NULL outputs are skipped.
+// ---------------------------------------------------------------------------
+template <typename T> struct EvalArgs {
+    int npts, integ;
+    T dt;
+    const T* params;
+    const T* x; const T* u;
+    T *f, *f_x, *f_u, *l, *l_x, *l_u, *l_xx, *l_ux, *l_uu, *l_f, *l_f_x, *l_f_xx;
+};
+
+template <typename T, typename Dyn>
+__global__ void __launch_bounds__(64) eval_points_kernel(EvalArgs<T> a) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    using PL = ParamLayout<Dyn::NSYS, NX, NU>;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.npts) return;
+    const T* __restrict__ p = a.params;
+    T x[NX], u[NU];
+#pragma unroll
+    for (int r = 0; r < NX; ++r) x[r] = a.x[(size_t)i * NX + r];
+#pragma unroll
+    for (int r = 0; r < NU; ++r) u[r] = a.u ? a.u[(size_t)i * NU + r] : T(0);
+    if (a.f_x || a.f_u) {
+        T xn[NX], fx[NX][NX], fu[NX][NU];
+        Stepper<T, Dyn>::step_jac(a.integ, p, a.dt, x, u, xn, fx, fu);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c)
+                if (a.f_x) a.f_x[((size_t)i * NX + r) * NX + c] = fx[r][c];
+#pragma unroll
+            for (int c = 0; c < NU; ++c)
+                if (a.f_u) a.f_u[((size_t)i * NX + r) * NU + c] = fu[r][c];
+        }
+    }
+    if (a.f) {
+        // the plain step, exactly what the rollout uses
+        T xn[NX];
+        Stepper<T, Dyn>::step(a.integ, p, a.dt, x, u, xn);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) a.f[(size_t)i * NX + r] = xn[r];
+    }
+    if (a.l) a.l[i] = Cost<T, Dyn>::stage(p, a.dt, x, u);
+    if (a.l_x) {
+        T g[NX];
+        Cost<T, Dyn>::l_x(p, a.dt, x, g);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) a.l_x[(size_t)i * NX + r] = g[r];
+    }
+    if (a.l_u) {
+        T g[NU];
+        Cost<T, Dyn>::l_u(p, a.dt, u, g);
+#pragma unroll
+        for (int r = 0; r < NU; ++r) a.l_u[(size_t)i * NU + r] = g[r];
+    }
+    if (a.l_xx)
+#pragma unroll
+        for (int r = 0; r < NX * NX; ++r) a.l_xx[(size_t)i * NX * NX + r] = p[PL::QS + r] * a.dt;
+    if (a.l_ux)
+#pragma unroll
+        for (int r = 0; r < NU * NX; ++r) a.l_ux[(size_t)i * NU * NX + r] = T(0);
+    if (a.l_uu)
+#pragma unroll
+        for (int r = 0; r < NU * NU; ++r) a.l_uu[(size_t)i * NU * NU + r] = p[PL::RS + r] * a.dt;
+    if (a.l_f) a.l_f[i] = Cost<T, Dyn>::terminal(p, x);
+    if (a.l_f_x) {
+        T g[NX];
+        Cost<T, Dyn>::l_f_x(p, x, g);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) a.l_f_x[(size_t)i * NX + r] = g[r];
+    }
+    if (a.l_f_xx)
+#pragma unroll
+        for (int r = 0; r < NX * NX; ++r) a.l_f_xx[(size_t)i * NX * NX + r] = p[PL::QFS + r];
+}
+
+// ---------------------------------------------------------------------------
+// MPC advance (run_iLQR_MPC.py:127-140): u0 = U[:,0]; plant step with the plant's own
+// integrator; x_0 <- new plant state; warm start <- shift(U) repeating the last column.
+// One lane per trajectory (the shift walks its own column in place: read t+1, write t).
+// ---------------------------------------------------------------------------
+template <typename T> struct MpcArgs {
+    int B, N, plant_integ, step;
+    T dt;
+    const T* params;
+    T* U; const int* cur_slot; T* x0; T* plant_x;
+    T* u_log; T* x_log; T* cost_log; const T* cost;  // logs: [n_steps][...][B] or NULL
+};
+
+template <typename T, typename Dyn>
+__global__ void __launch_bounds__(64) mpc_advance_kernel(MpcArgs<T> a) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    const size_t B = a.B;
+    T* Uc = a.U + ((size_t)a.cur_slot[b] * a.N * NU) * B + b;
+    T x[NX], u[NU], xn[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = a.plant_x[(size_t)i * B + b];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) u[j] = Uc[(size_t)j * B];
+    Stepper<T, Dyn>::step(a.plant_integ, a.params, a.dt, x, u, xn);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        a.plant_x[(size_t)i * B + b] = xn[i];
+        a.x0[(size_t)i * B + b] = xn[i];
+        if (a.x_log) a.x_log[((size_t)a.step * NX + i) * B + b] = xn[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+        if (a.u_log) a.u_log[((size_t)a.step * NU + j) * B + b] = u[j];
+    if (a.cost_log) a.cost_log[(size_t)a.step * B + b] = a.cost[b];
+    for (int t = 0; t + 1 < a.N; ++t)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) Uc[((size_t)t * NU + j) * B] = Uc[((size_t)(t + 1) * NU + j) * B];
+}
+
+// ---------------------------------------------------------------------------
+// layout conversion between the host layouts of the C-ABI (leading batch axis in
+// front of the reference layout) and the device's batch-innermost slots.
+// dense[b][c][t] (c = component, t = time) <-> slots[slot(b)][t][c][b]
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void scatter_ct_kernel(const T* dense, T* slots, const int* cur_slot, int B, int C, int Tn) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C * Tn) return;
+    const int b = (int)(idx % B);
+    const int c = (int)((idx / B) % C);
+    const int t = (int)(idx / ((size_t)B * C));
+    const int s = cur_slot ? cur_slot[b] : 0;
+    slots[(((size_t)s * Tn + t) * C + c) * B + b] = dense[((size_t)b * C + c) * Tn + t];
+}
+template <typename T>
+__global__ void gather_ct_kernel(T* dense, const T* slots, const int* cur_slot, int B, int C, int Tn) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C * Tn) return;
+    const int b = (int)(idx % B);
+    const int c = (int)((idx / B) % C);
+    const int t = (int)(idx / ((size_t)B * C));
+    const int s = cur_slot ? cur_slot[b] : 0;
+    dense[((size_t)b * C + c) * Tn + t] = slots[(((size_t)s * Tn + t) * C + c) * B + b];
+}
+// dense[b][t][c] <-> dev[t][c][b]   (K, ILQR_LIN, x0 with Tn = 1)
+template <typename T>
+__global__ void scatter_tc_kernel(const T* dense, T* dev, int B, int C, int Tn) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C * Tn) return;
+    const int b = (int)(idx % B);
+    const int c = (int)((idx / B) % C);
+    const int t = (int)(idx / ((size_t)B * C));
+    dev[((size_t)t * C + c) * B + b] = dense[((size_t)b * Tn + t) * C + c];
+}
+template <typename T>
+__global__ void gather_tc_kernel(T* dense, const T* dev, int B, int C, int Tn) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * C * Tn) return;
+    const int b = (int)(idx % B);
+    const int c = (int)((idx / B) % C);
+    const int t = (int)(idx / ((size_t)B * C));
+    dense[((size_t)b * Tn + t) * C + c] = dev[((size_t)t * C + c) * B + b];
+}
+
+}  // namespace ilqr

@@ -1,0 +1,733 @@
+// solver.hpp -- host side of libilqr_hip.so: the handle behind the C-ABI.
+//
+// SolverBase is the dtype-erased interface the extern "C" layer (ilqr_abi.cpp)
+// talks to; SolverT<T> owns the device buffers, the stream and the launch
+// sequence of the hot path.  It mirrors the state and the control flow of the
+// reference's iLQR class (python/class_files/iLQR_class.py:18-75, 250-313) for a
+// whole batch of trajectories at once, with the per-trajectory loop state
+// (cost, status, iteration count) kept on the device so an iteration needs no
+// host round trip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace ilqr {
+
+struct SolverBase {
+    ilqr_config cfg{};
+    std::string err;
+    virtual ~SolverBase() {}
+    virtual int sync() = 0;
+    virtual int set_problem(const void* x0, const void* U) = 0;
+    virtual int set(int field, const void* src, size_t bytes) = 0;
+    virtual int get(int field, void* dst, size_t bytes) = 0;
+    virtual int initial_rollout() = 0;
+    virtual int linearize() = 0;
+    virtual int backward() = 0;
+    virtual int forward(const double* alphas, int n) = 0;
+    virtual int select() = 0;
+    virtual int iterate(int n) = 0;
+    virtual int solve(int32_t* iters, void* cost) = 0;
+    virtual int backward_pass(const void* X, const void* U, void* Uff, void* K) = 0;
+    virtual int forward_pass(const void* x0, double alpha, const void* X, const void* U, const void* Uff,
+                             const void* K, void* Xn, void* Un, void* cost) = 0;
+    virtual int eval_points(int integ, int npts, const void* x, const void* u, void** outs) = 0;
+    virtual int mpc_reset(const void* x0, const void* U) = 0;
+    virtual int mpc_run(int n_steps, void* u_out, void* x_out, void* cost_out) = 0;
+    virtual int timing_enable(int on) = 0;
+    virtual int timing_reset() = 0;
+    virtual int timing_get(double* ms, int64_t* launches) = 0;
+    virtual int algorithmic_bytes(double* bytes) = 0;
+};
+
+int system_dims(int system, int n_x, int n_u);  // 1 if (system, n_x, n_u) is a known combination
+int param_count(int system, int n_x, int n_u);
+int n_sys_params_abi(int system, int n_x, int n_u);
+SolverBase* make_solver_f32(const ilqr_config& cfg, std::string& err, int* status);
+SolverBase* make_solver_f64(const ilqr_config& cfg, std::string& err, int* status);
+bool supported_f32(int system, int n_x, int n_u);
+bool supported_f64(int system, int n_x, int n_u);
+
+#define ILQR_HIPCHK(expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            this->err = std::string(#expr) + ": " + hipGetErrorString(e_);                     \
+            return ILQR_ERR_HIP;                                                               \
+        }                                                                                      \
+    } while (0)
+
+template <typename T> struct Ops {
+    void (*linearize)(const KArgs<T>&, hipStream_t) = nullptr;
+    void (*backward)(const KArgs<T>&, hipStream_t) = nullptr;
+    void (*forward)(const KArgs<T>&, hipStream_t) = nullptr;
+    void (*eval)(const EvalArgs<T>&, hipStream_t) = nullptr;
+    void (*mpc_advance)(const MpcArgs<T>&, hipStream_t) = nullptr;
+    int n_dev_params = 0;
+    int n_sys_dev = 0;
+};
+
+template <typename T, typename Dyn> Ops<T> make_ops() {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    Ops<T> o;
+    o.linearize = [](const KArgs<T>& a, hipStream_t s) {
+        const size_t total = (size_t)a.B * (a.N + 1);
+        hipLaunchKernelGGL((linearize_kernel<T, Dyn>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    };
+    o.backward = [](const KArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((backward_lane_kernel<T, NX, NU>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+    };
+    o.forward = [](const KArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((forward_kernel<T, Dyn>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+    };
+    o.eval = [](const EvalArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((eval_points_kernel<T, Dyn>), dim3((a.npts + 63) / 64), dim3(64), 0, s, a);
+    };
+    o.mpc_advance = [](const MpcArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((mpc_advance_kernel<T, Dyn>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+    };
+    o.n_dev_params = ParamLayout<Dyn::NSYS, NX, NU>::TOTAL;
+    o.n_sys_dev = Dyn::NSYS;
+    return o;
+}
+
+template <typename T> bool find_ops(int system, int nx, int nu, Ops<T>* out);
+
+// host: ABI parameter block (doubles) -> device parameter block (see dynamics.hpp)
+inline std::vector<double> build_device_params(int system, int nx, int nu, const double* p) {
+    std::vector<double> d;
+    const double* q = p;
+    if (system == ILQR_SYS_PENDULUM) {
+        const double g = p[0], l = p[1], dd = p[2];
+        d = {g / l, dd};
+        q = p + 3;
+    } else if (system == ILQR_SYS_UA_DOUBLE_PENDULUM || system == ILQR_SYS_DOUBLE_PENDULUM) {
+        const double g = p[0], m1 = p[1], m2 = p[2], l1 = p[3], l2 = p[4], d1 = p[5], d2 = p[6], th1 = p[7],
+                     th2 = p[8];
+        d = {m2 * l1 * l2,
+             (m1 * l1 * l1) / 4 + m2 * l1 * l1 + (m2 * l2 * l2) / 4 + th1 + th2,
+             (m2 * l2 * l2) / 4 + th2,
+             m2 * g * l2 / 2,
+             (m2 + m1 / 2) * g * l1,
+             d1,
+             d2};
+        q = p + 9;
+    } else {  // linear: A, B verbatim
+        d.assign(p, p + nx * nx + nx * nu);
+        q = p + nx * nx + nx * nu;
+    }
+    const double* xt = q;
+    const double* Q = xt + nx;
+    const double* R = Q + nx * nx;
+    const double* Qf = R + nu * nu;
+    d.insert(d.end(), xt, xt + nx);
+    d.insert(d.end(), Q, Q + nx * nx);
+    d.insert(d.end(), R, R + nu * nu);
+    d.insert(d.end(), Qf, Qf + nx * nx);
+    auto sym = [&](const double* A, int n) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) d.push_back(0.5 * (A[i * n + j] + A[j * n + i]));
+    };
+    sym(Q, nx);
+    sym(R, nu);
+    sym(Qf, nx);
+    return d;
+}
+
+struct PhaseTimer {
+    struct Rec { int phase; hipEvent_t a, b; };
+    bool on = false;
+    std::vector<Rec> pending;
+    std::vector<hipEvent_t> pool;
+    double ms[ILQR_N_PHASES] = {0};
+    int64_t n[ILQR_N_PHASES] = {0};
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        hipEventCreate(&e);
+        return e;
+    }
+    void begin(int phase, hipStream_t s) {
+        if (!on) return;
+        Rec r{phase, get_event(), get_event()};
+        hipEventRecord(r.a, s);
+        pending.push_back(r);
+    }
+    void end(hipStream_t s) {
+        if (!on) return;
+        hipEventRecord(pending.back().b, s);
+        if (pending.size() >= 8192) resolve(s);
+    }
+    void resolve(hipStream_t s) {
+        if (pending.empty()) return;
+        hipStreamSynchronize(s);
+        for (auto& r : pending) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, r.a, r.b);
+            ms[r.phase] += t;
+            n[r.phase] += 1;
+            pool.push_back(r.a);
+            pool.push_back(r.b);
+        }
+        pending.clear();
+    }
+    void reset(hipStream_t s) {
+        resolve(s);
+        for (int i = 0; i < ILQR_N_PHASES; ++i) { ms[i] = 0; n[i] = 0; }
+    }
+    ~PhaseTimer() {
+        for (auto& r : pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
+        for (auto e : pool) hipEventDestroy(e);
+    }
+};
+
+// One set of device state: the solver proper, and a second, smaller one used by the
+// pure functional calls (backward_pass / forward_pass) so they never disturb the solver.
+template <typename T> struct DeviceState {
+    int n_slots = 0;
+    T *X = nullptr, *U = nullptr, *K = nullptr, *kff = nullptr, *lin = nullptr, *term = nullptr, *x0 = nullptr;
+    T *costs = nullptr, *cost = nullptr, *cost_prev = nullptr, *alpha_taken = nullptr;
+    int *cur_slot = nullptr, *status = nullptr, *iters = nullptr, *accepted = nullptr, *counters = nullptr;
+};
+
+template <typename T> class SolverT : public SolverBase {
+  public:
+    int B, N, NX, NU, E, A;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Ops<T> ops;
+    T* params = nullptr;
+    DeviceState<T> st, fn;  // solver state, functional-call scratch state
+    T* staging = nullptr;   // dense staging for layout conversion
+    size_t staging_elems = 0;
+    T* plant_x = nullptr;
+    T *mpc_u_log = nullptr, *mpc_x_log = nullptr, *mpc_cost_log = nullptr;
+    int mpc_log_steps = 0;
+    int* h_counter = nullptr;  // pinned
+    std::vector<double> trial_alphas;
+    PhaseTimer timer;
+    bool have_problem = false, have_rollout = false, mpc_ready = false;
+    int iter_seq = 0;
+
+    ~SolverT() override {
+        if (stream) hipStreamSynchronize(stream);
+        free_state(st);
+        free_state(fn);
+        hipFree(params);
+        hipFree(staging);
+        hipFree(plant_x);
+        hipFree(mpc_u_log);
+        hipFree(mpc_x_log);
+        hipFree(mpc_cost_log);
+        if (h_counter) hipHostFree(h_counter);
+        if (own_stream && stream) hipStreamDestroy(stream);
+    }
+
+    static void free_state(DeviceState<T>& s) {
+        hipFree(s.X); hipFree(s.U); hipFree(s.K); hipFree(s.kff); hipFree(s.lin); hipFree(s.term); hipFree(s.x0);
+        hipFree(s.costs); hipFree(s.cost); hipFree(s.cost_prev); hipFree(s.alpha_taken);
+        hipFree(s.cur_slot); hipFree(s.status); hipFree(s.iters); hipFree(s.accepted); hipFree(s.counters);
+        s = DeviceState<T>();
+    }
+
+    int alloc_state(DeviceState<T>& s, int n_slots) {
+        s.n_slots = n_slots;
+        const size_t b = B;
+        auto al = [&](auto** p, size_t n) -> hipError_t {
+            hipError_t e = hipMalloc((void**)p, n * sizeof(**p));
+            if (e == hipSuccess) e = hipMemsetAsync(*p, 0, n * sizeof(**p), stream);
+            return e;
+        };
+        ILQR_HIPCHK(al(&s.X, (size_t)n_slots * (N + 1) * NX * b));
+        ILQR_HIPCHK(al(&s.U, (size_t)n_slots * N * NU * b));
+        ILQR_HIPCHK(al(&s.K, (size_t)N * NU * NX * b));
+        ILQR_HIPCHK(al(&s.kff, (size_t)N * NU * b));
+        ILQR_HIPCHK(al(&s.lin, (size_t)N * E * b));
+        ILQR_HIPCHK(al(&s.term, (size_t)(NX + NX * NX) * b));
+        ILQR_HIPCHK(al(&s.x0, (size_t)NX * b));
+        ILQR_HIPCHK(al(&s.costs, (size_t)kMaxAlpha * b));
+        ILQR_HIPCHK(al(&s.cost, b));
+        ILQR_HIPCHK(al(&s.cost_prev, b));
+        ILQR_HIPCHK(al(&s.alpha_taken, b));
+        ILQR_HIPCHK(al(&s.cur_slot, b));
+        ILQR_HIPCHK(al(&s.status, b));
+        ILQR_HIPCHK(al(&s.iters, b));
+        ILQR_HIPCHK(al(&s.accepted, b));
+        ILQR_HIPCHK(al(&s.counters, (size_t)kCounterRing));
+        return ILQR_OK;
+    }
+
+    int init(const ilqr_config& c) {
+        cfg = c;
+        B = c.batch; N = c.horizon; NX = c.n_x; NU = c.n_u; A = c.n_alpha;
+        E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+        if (!find_ops<T>(c.system, NX, NU, &ops)) {
+            err = "no kernels compiled for this (system, n_x, n_u, dtype)";
+            return ILQR_ERR_UNSUPPORTED;
+        }
+        ILQR_HIPCHK(hipSetDevice(c.device));
+        if (c.stream) {
+            stream = (hipStream_t)c.stream;
+        } else {
+            ILQR_HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+            own_stream = true;
+        }
+        // backtracking schedule exactly as the Python loop builds it (iLQR_class.py:279-302)
+        double al = 1.0;
+        for (int j = 0; j < c.n_trials; ++j) {
+            trial_alphas.push_back(al);
+            al *= c.alpha_factor;
+            if (al < c.min_alpha) break;
+        }
+        std::vector<double> dp = build_device_params(c.system, NX, NU, c.params);
+        if ((int)dp.size() != ops.n_dev_params) { err = "internal: device parameter block size mismatch"; return ILQR_ERR_INVALID_ARG; }
+        std::vector<T> dpt(dp.begin(), dp.end());
+        ILQR_HIPCHK(hipMalloc((void**)&params, dpt.size() * sizeof(T)));
+        ILQR_HIPCHK(hipMemcpy(params, dpt.data(), dpt.size() * sizeof(T), hipMemcpyHostToDevice));
+        int rc = alloc_state(st, A + 1);
+        if (rc) return rc;
+        staging_elems = (size_t)B * std::max((size_t)(N + 1) * NX, std::max((size_t)N * NU * NX, (size_t)N * E));
+        ILQR_HIPCHK(hipMalloc((void**)&staging, staging_elems * sizeof(T)));
+        ILQR_HIPCHK(hipMalloc((void**)&plant_x, (size_t)NX * B * sizeof(T)));
+        ILQR_HIPCHK(hipMemsetAsync(plant_x, 0, (size_t)NX * B * sizeof(T), stream));
+        ILQR_HIPCHK(hipHostMalloc((void**)&h_counter, kCounterRing * sizeof(int)));
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return ILQR_OK;
+    }
+
+    KArgs<T> kargs(const DeviceState<T>& s) const {
+        KArgs<T> a{};
+        a.B = B; a.N = N; a.n_slots = s.n_slots; a.integ = cfg.integrator; a.maxiter = cfg.maxiter; a.flags = cfg.flags;
+        a.dt = (T)cfg.dt; a.tol = (T)cfg.tol; a.mu = (T)cfg.mu;
+        a.X = s.X; a.U = s.U; a.cur_slot = s.cur_slot; a.K = s.K; a.kff = s.kff; a.lin = s.lin; a.term = s.term;
+        a.x0 = s.x0; a.costs = s.costs; a.cost = s.cost; a.cost_prev = s.cost_prev; a.alpha_taken = s.alpha_taken;
+        a.status = s.status; a.iters = s.iters; a.accepted = s.accepted; a.counters = s.counters; a.params = params;
+        return a;
+    }
+
+    int check_launch() {
+        ILQR_HIPCHK(hipGetLastError());
+        return ILQR_OK;
+    }
+
+    int sync() override {
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return ILQR_OK;
+    }
+
+    // ---- layout conversion helpers (dense host layout <-> device) ------------------
+    unsigned grid_for(size_t n) const { return (unsigned)((n + 255) / 256); }
+
+    int up_ct(const void* host, T* slots, const int* cur_slot, int C, int Tn) {
+        const size_t n = (size_t)B * C * Tn;
+        ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(scatter_ct_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, slots, cur_slot, B, C, Tn);
+        ILQR_HIPCHK(hipStreamSynchronize(stream));  // the caller's host buffer may be released after return
+        return check_launch();
+    }
+    int down_ct(void* host, const T* slots, const int* cur_slot, int C, int Tn) {
+        const size_t n = (size_t)B * C * Tn;
+        hipLaunchKernelGGL(gather_ct_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, slots, cur_slot, B, C, Tn);
+        ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+    int up_tc(const void* host, T* dev, int C, int Tn) {
+        const size_t n = (size_t)B * C * Tn;
+        ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(scatter_tc_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, dev, B, C, Tn);
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+    int down_tc(void* host, const T* dev, int C, int Tn) {
+        const size_t n = (size_t)B * C * Tn;
+        hipLaunchKernelGGL(gather_tc_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, dev, B, C, Tn);
+        ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+
+    int zero_solver_state(DeviceState<T>& s) {
+        const size_t b = B;
+        ILQR_HIPCHK(hipMemsetAsync(s.X, 0, (size_t)s.n_slots * (N + 1) * NX * b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.U, 0, (size_t)s.n_slots * N * NU * b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.K, 0, (size_t)N * NU * NX * b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.kff, 0, (size_t)N * NU * b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.cur_slot, 0, b * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.status, 0, b * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.iters, 0, b * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.accepted, 0, b * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.cost, 0, b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.cost_prev, 0, b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.alpha_taken, 0, b * sizeof(T), stream));
+        return ILQR_OK;
+    }
+
+    // fresh solver as after iLQR.__init__ (iLQR_class.py:55-61)
+    int set_problem(const void* x0, const void* U) override {
+        if (!x0 || !U) { err = "set_problem: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        int rc = zero_solver_state(st);
+        if (rc) return rc;
+        if ((rc = up_tc(x0, st.x0, NX, 1))) return rc;
+        if ((rc = up_ct(U, st.U, st.cur_slot, NU, N))) return rc;
+        have_problem = true;
+        have_rollout = false;
+        return ILQR_OK;
+    }
+
+    size_t field_bytes(int field) const {
+        const size_t b = B;
+        switch (field) {
+            case ILQR_X: return b * NX * (N + 1) * sizeof(T);
+            case ILQR_U: case ILQR_UFF: return b * NU * N * sizeof(T);
+            case ILQR_K: return b * N * NU * NX * sizeof(T);
+            case ILQR_X0: case ILQR_PLANT_X: return b * NX * sizeof(T);
+            case ILQR_COST: case ILQR_ALPHA: return b * sizeof(T);
+            case ILQR_STATUS: case ILQR_ITERS: return b * sizeof(int32_t);
+            case ILQR_TRIAL_COSTS: return b * A * sizeof(T);
+            case ILQR_LIN: return b * N * E * sizeof(T);
+            default: return 0;
+        }
+    }
+
+    int set(int field, const void* src, size_t bytes) override {
+        if (!src) { err = "set: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        const size_t want = field_bytes(field);
+        if (want == 0 || bytes != want) { err = "set: unknown field or wrong byte count"; return ILQR_ERR_INVALID_ARG; }
+        switch (field) {
+            case ILQR_X: return up_ct(src, st.X, st.cur_slot, NX, N + 1);
+            case ILQR_U: return up_ct(src, st.U, st.cur_slot, NU, N);
+            case ILQR_UFF: return up_ct(src, st.kff, nullptr, NU, N);
+            case ILQR_K: return up_tc(src, st.K, NU * NX, N);
+            case ILQR_X0: return up_tc(src, st.x0, NX, 1);
+            case ILQR_PLANT_X: return up_tc(src, plant_x, NX, 1);
+            default: err = "set: field is read-only"; return ILQR_ERR_INVALID_ARG;
+        }
+    }
+
+    int get(int field, void* dst, size_t bytes) override {
+        if (!dst) { err = "get: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        const size_t want = field_bytes(field);
+        if (want == 0 || bytes != want) { err = "get: unknown field or wrong byte count"; return ILQR_ERR_INVALID_ARG; }
+        switch (field) {
+            case ILQR_X: return down_ct(dst, st.X, st.cur_slot, NX, N + 1);
+            case ILQR_U: return down_ct(dst, st.U, st.cur_slot, NU, N);
+            case ILQR_UFF: return down_ct(dst, st.kff, nullptr, NU, N);
+            case ILQR_K: return down_tc(dst, st.K, NU * NX, N);
+            case ILQR_X0: return down_tc(dst, st.x0, NX, 1);
+            case ILQR_PLANT_X: return down_tc(dst, plant_x, NX, 1);
+            case ILQR_LIN: return down_tc(dst, st.lin, E, N);
+            case ILQR_TRIAL_COSTS: return down_tc(dst, st.costs, A, 1);
+            case ILQR_COST: ILQR_HIPCHK(hipMemcpyAsync(dst, st.cost, bytes, hipMemcpyDeviceToHost, stream)); return sync();
+            case ILQR_ALPHA: ILQR_HIPCHK(hipMemcpyAsync(dst, st.alpha_taken, bytes, hipMemcpyDeviceToHost, stream)); return sync();
+            case ILQR_STATUS: ILQR_HIPCHK(hipMemcpyAsync(dst, st.status, bytes, hipMemcpyDeviceToHost, stream)); return sync();
+            case ILQR_ITERS: ILQR_HIPCHK(hipMemcpyAsync(dst, st.iters, bytes, hipMemcpyDeviceToHost, stream)); return sync();
+            default: err = "get: unknown field"; return ILQR_ERR_INVALID_ARG;
+        }
+    }
+
+    // ---- stages ---------------------------------------------------------------------
+    int do_linearize(DeviceState<T>& s) {
+        KArgs<T> a = kargs(s);
+        timer.begin(ILQR_PHASE_LINEARIZE, stream);
+        ops.linearize(a, stream);
+        timer.end(stream);
+        return check_launch();
+    }
+    int do_backward(DeviceState<T>& s) {
+        KArgs<T> a = kargs(s);
+        timer.begin(ILQR_PHASE_BACKWARD, stream);
+        ops.backward(a, stream);
+        timer.end(stream);
+        return check_launch();
+    }
+    int do_forward(DeviceState<T>& s, const double* alphas, int n) {
+        if (n < 1 || n > s.n_slots - 1 || n > kMaxAlpha) { err = "forward: alpha count out of range"; return ILQR_ERR_INVALID_ARG; }
+        KArgs<T> a = kargs(s);
+        a.n_pass = n;
+        for (int i = 0; i < n; ++i) a.alphas[i] = (T)alphas[i];
+        timer.begin(ILQR_PHASE_FORWARD, stream);
+        ops.forward(a, stream);
+        timer.end(stream);
+        return check_launch();
+    }
+    int do_select(DeviceState<T>& s, const double* alphas, int n, bool last, bool init, int counter_idx) {
+        KArgs<T> a = kargs(s);
+        a.n_pass = n; a.last_pass = last; a.init_mode = init; a.counter_idx = counter_idx;
+        for (int i = 0; i < n; ++i) a.alphas[i] = (T)alphas[i];
+        timer.begin(ILQR_PHASE_SELECT, stream);
+        hipLaunchKernelGGL(select_kernel<T>, dim3((B + 255) / 256), dim3(256), 0, stream, a);
+        timer.end(stream);
+        return check_launch();
+    }
+
+    int pending_n = 0;
+    double pending_alphas[kMaxAlpha];
+
+    int initial_rollout() override {
+        if (!have_problem) { err = "initial_rollout before set_problem"; return ILQR_ERR_STATE; }
+        int rc;
+        // all trajectories take part in the head of a solve, whatever their previous status
+        ILQR_HIPCHK(hipMemsetAsync(st.status, 0, (size_t)B * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(st.accepted, 0, (size_t)B * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(st.counters, 0, kCounterRing * sizeof(int), stream));
+        const double zero = 0.0;
+        if ((rc = do_forward(st, &zero, 1))) return rc;
+        if ((rc = do_select(st, &zero, 1, false, true, 0))) return rc;
+        have_rollout = true;
+        iter_seq = 0;
+        return ILQR_OK;
+    }
+    int linearize() override {
+        if (!have_problem) { err = "linearize before set_problem"; return ILQR_ERR_STATE; }
+        return do_linearize(st);
+    }
+    int backward() override {
+        if (!have_problem) { err = "backward before set_problem"; return ILQR_ERR_STATE; }
+        return do_backward(st);
+    }
+    int forward(const double* alphas, int n) override {
+        if (!have_rollout) { err = "forward before initial_rollout"; return ILQR_ERR_STATE; }
+        if (!alphas) { err = "forward: NULL alphas"; return ILQR_ERR_INVALID_ARG; }
+        if (n < 1 || n > A) { err = "forward: alpha count must be in [1, n_alpha]"; return ILQR_ERR_INVALID_ARG; }
+        int rc = do_forward(st, alphas, n);
+        if (rc) return rc;
+        pending_n = n;
+        for (int i = 0; i < n; ++i) pending_alphas[i] = alphas[i];
+        return ILQR_OK;
+    }
+    int select() override {
+        if (pending_n == 0) { err = "select without a preceding forward"; return ILQR_ERR_STATE; }
+        int rc = do_select(st, pending_alphas, pending_n, true, false, next_counter());
+        pending_n = 0;
+        return rc;
+    }
+
+    int next_counter() {
+        iter_seq += 1;
+        return iter_seq % kCounterRing;
+    }
+
+    // one iLQR iteration for the whole batch; returns the ring index that will hold the
+    // number of trajectories still active after it
+    int one_iteration(int* counter_idx) {
+        int rc;
+        if ((rc = do_linearize(st))) return rc;
+        if ((rc = do_backward(st))) return rc;
+        const int total = (int)trial_alphas.size();
+        const int cidx = next_counter();
+        ILQR_HIPCHK(hipMemsetAsync(st.counters + cidx, 0, sizeof(int), stream));
+        for (int base = 0; base < total; base += A) {
+            const int n = std::min(A, total - base);
+            const bool last = (base + n >= total);
+            if ((rc = do_forward(st, trial_alphas.data() + base, n))) return rc;
+            if ((rc = do_select(st, trial_alphas.data() + base, n, last, false, cidx))) return rc;
+        }
+        if (counter_idx) *counter_idx = cidx;
+        return ILQR_OK;
+    }
+
+    int iterate(int n) override {
+        if (!have_rollout) { err = "iterate before initial_rollout"; return ILQR_ERR_STATE; }
+        for (int i = 0; i < n; ++i) {
+            int rc = one_iteration(nullptr);
+            if (rc) return rc;
+        }
+        return ILQR_OK;
+    }
+
+    // optimize_trajectory (iLQR_class.py:250-313) for the batch.  The per-trajectory loop
+    // state lives on the device; the host only learns how many trajectories are still active,
+    // one iteration late (so the stream never drains), and stops launching when none is.
+    int run_solve_loop() {
+        int rc;
+        if ((rc = initial_rollout())) return rc;
+        for (int i = 0; i < cfg.maxiter; ++i) {
+            int cidx;
+            if ((rc = one_iteration(&cidx))) return rc;
+            // inactive trajectories are skipped inside every kernel, so the only reason to look
+            // at the count is to stop launching once nobody is left
+            ILQR_HIPCHK(hipMemcpyAsync(h_counter + cidx, st.counters + cidx, sizeof(int), hipMemcpyDeviceToHost, stream));
+            ILQR_HIPCHK(hipStreamSynchronize(stream));
+            if (h_counter[cidx] == 0) break;
+        }
+        return ILQR_OK;
+    }
+
+    int solve(int32_t* iters, void* cost) override {
+        if (!have_problem) { err = "solve before set_problem"; return ILQR_ERR_STATE; }
+        int rc = run_solve_loop();
+        if (rc) return rc;
+        if (iters) ILQR_HIPCHK(hipMemcpyAsync(iters, st.iters, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (cost) ILQR_HIPCHK(hipMemcpyAsync(cost, st.cost, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, stream));
+        return sync();
+    }
+
+    // ---- pure functional calls --------------------------------------------------------
+    int ensure_fn() {
+        if (fn.X) return ILQR_OK;
+        int rc = alloc_state(fn, 2);
+        if (rc) return rc;
+        return ILQR_OK;
+    }
+    int reset_fn() {
+        const size_t b = B;
+        ILQR_HIPCHK(hipMemsetAsync(fn.cur_slot, 0, b * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(fn.status, 0, b * sizeof(int), stream));
+        ILQR_HIPCHK(hipMemsetAsync(fn.accepted, 0, b * sizeof(int), stream));
+        return ILQR_OK;
+    }
+
+    int backward_pass(const void* X, const void* U, void* Uff, void* K) override {
+        if (!X || !U) { err = "backward_pass: NULL input"; return ILQR_ERR_INVALID_ARG; }
+        int rc;
+        if ((rc = ensure_fn()) || (rc = reset_fn())) return rc;
+        if ((rc = up_ct(X, fn.X, nullptr, NX, N + 1))) return rc;
+        if ((rc = up_ct(U, fn.U, nullptr, NU, N))) return rc;
+        if ((rc = do_linearize(fn))) return rc;
+        if ((rc = do_backward(fn))) return rc;
+        if (Uff && (rc = down_ct(Uff, fn.kff, nullptr, NU, N))) return rc;
+        if (K && (rc = down_tc(K, fn.K, NU * NX, N))) return rc;
+        return sync();
+    }
+
+    int forward_pass(const void* x0, double alpha, const void* X, const void* U, const void* Uff, const void* K,
+                     void* Xn, void* Un, void* cost) override {
+        if (!x0 || !X || !U || !Uff || !K) { err = "forward_pass: NULL input"; return ILQR_ERR_INVALID_ARG; }
+        int rc;
+        if ((rc = ensure_fn()) || (rc = reset_fn())) return rc;
+        if ((rc = up_tc(x0, fn.x0, NX, 1))) return rc;
+        if ((rc = up_ct(X, fn.X, nullptr, NX, N + 1))) return rc;
+        if ((rc = up_ct(U, fn.U, nullptr, NU, N))) return rc;
+        if ((rc = up_ct(Uff, fn.kff, nullptr, NU, N))) return rc;
+        if ((rc = up_tc(K, fn.K, NU * NX, N))) return rc;
+        if ((rc = do_forward(fn, &alpha, 1))) return rc;
+        // the candidate went to slot 1: read it back from there
+        T* X1 = fn.X + (size_t)(N + 1) * NX * B;
+        T* U1 = fn.U + (size_t)N * NU * B;
+        if (Xn && (rc = down_ct(Xn, X1, nullptr, NX, N + 1))) return rc;
+        if (Un && (rc = down_ct(Un, U1, nullptr, NU, N))) return rc;
+        if (cost) ILQR_HIPCHK(hipMemcpyAsync(cost, fn.costs, (size_t)B * sizeof(T), hipMemcpyDeviceToHost, stream));
+        return sync();
+    }
+
+    int eval_points(int integ, int npts, const void* x, const void* u, void** outs) override {
+        if (npts < 1 || !x) { err = "eval_points: bad arguments"; return ILQR_ERR_INVALID_ARG; }
+        const size_t sizes[12] = {(size_t)NX, (size_t)NX * NX, (size_t)NX * NU, 1, (size_t)NX, (size_t)NU,
+                                  (size_t)NX * NX, (size_t)NU * NX, (size_t)NU * NU, 1, (size_t)NX, (size_t)NX * NX};
+        size_t total = (size_t)NX + NU;
+        for (int i = 0; i < 12; ++i) total += sizes[i];
+        T* buf = nullptr;
+        ILQR_HIPCHK(hipMalloc((void**)&buf, total * npts * sizeof(T)));
+        T* dx = buf;
+        T* du = dx + (size_t)npts * NX;
+        T* cur = du + (size_t)npts * NU;
+        T* dout[12];
+        for (int i = 0; i < 12; ++i) {
+            dout[i] = outs[i] ? cur : nullptr;
+            cur += sizes[i] * npts;
+        }
+        hipError_t e = hipMemcpyAsync(dx, x, (size_t)npts * NX * sizeof(T), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && u) e = hipMemcpyAsync(du, u, (size_t)npts * NU * sizeof(T), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess && !u) e = hipMemsetAsync(du, 0, (size_t)npts * NU * sizeof(T), stream);
+        if (e == hipSuccess) {
+            EvalArgs<T> a{};
+            a.npts = npts; a.integ = integ < 0 ? cfg.integrator : integ; a.dt = (T)cfg.dt; a.params = params;
+            a.x = dx; a.u = du;
+            a.f = dout[0]; a.f_x = dout[1]; a.f_u = dout[2]; a.l = dout[3]; a.l_x = dout[4]; a.l_u = dout[5];
+            a.l_xx = dout[6]; a.l_ux = dout[7]; a.l_uu = dout[8]; a.l_f = dout[9]; a.l_f_x = dout[10]; a.l_f_xx = dout[11];
+            ops.eval(a, stream);
+            e = hipGetLastError();
+        }
+        for (int i = 0; i < 12 && e == hipSuccess; ++i)
+            if (outs[i]) e = hipMemcpyAsync(outs[i], dout[i], sizes[i] * npts * sizeof(T), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        hipFree(buf);
+        if (e != hipSuccess) { err = std::string("eval_points: ") + hipGetErrorString(e); return ILQR_ERR_HIP; }
+        return ILQR_OK;
+    }
+
+    // ---- MPC ----------------------------------------------------------------------------
+    int mpc_reset(const void* x0, const void* U) override {
+        int rc = set_problem(x0, U);
+        if (rc) return rc;
+        if ((rc = up_tc(x0, plant_x, NX, 1))) return rc;
+        mpc_ready = true;
+        return ILQR_OK;
+    }
+
+    int mpc_run(int n_steps, void* u_out, void* x_out, void* cost_out) override {
+        if (!mpc_ready) { err = "mpc_run before mpc_reset"; return ILQR_ERR_STATE; }
+        if (cfg.plant_integrator < 0) { err = "mpc_run: the handle was created without a plant integrator"; return ILQR_ERR_STATE; }
+        if (n_steps < 1) { err = "mpc_run: n_steps < 1"; return ILQR_ERR_INVALID_ARG; }
+        if (n_steps > mpc_log_steps) {
+            hipFree(mpc_u_log); hipFree(mpc_x_log); hipFree(mpc_cost_log);
+            mpc_u_log = mpc_x_log = mpc_cost_log = nullptr;
+            ILQR_HIPCHK(hipMalloc((void**)&mpc_u_log, (size_t)n_steps * NU * B * sizeof(T)));
+            ILQR_HIPCHK(hipMalloc((void**)&mpc_x_log, (size_t)n_steps * NX * B * sizeof(T)));
+            ILQR_HIPCHK(hipMalloc((void**)&mpc_cost_log, (size_t)n_steps * B * sizeof(T)));
+            mpc_log_steps = n_steps;
+        }
+        for (int k = 0; k < n_steps; ++k) {
+            int rc = run_solve_loop();
+            if (rc) return rc;
+            MpcArgs<T> m{};
+            m.B = B; m.N = N; m.plant_integ = cfg.plant_integrator; m.step = k; m.dt = (T)cfg.dt; m.params = params;
+            m.U = st.U; m.cur_slot = st.cur_slot; m.x0 = st.x0; m.plant_x = plant_x;
+            m.u_log = mpc_u_log; m.x_log = mpc_x_log; m.cost_log = mpc_cost_log; m.cost = st.cost;
+            timer.begin(ILQR_PHASE_OTHER, stream);
+            ops.mpc_advance(m, stream);
+            timer.end(stream);
+            if ((rc = check_launch())) return rc;
+        }
+        // logs are [step][c][B] on the device; the ABI promises [step][B][c]
+        std::vector<T> tmp;
+        auto fetch = [&](void* host, const T* dev, int C) -> int {
+            if (!host) return ILQR_OK;
+            tmp.resize((size_t)n_steps * C * B);
+            ILQR_HIPCHK(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+            ILQR_HIPCHK(hipStreamSynchronize(stream));
+            T* out = (T*)host;
+            for (int s = 0; s < n_steps; ++s)
+                for (int c = 0; c < C; ++c)
+                    for (int b = 0; b < B; ++b) out[((size_t)s * B + b) * C + c] = tmp[((size_t)s * C + c) * B + b];
+            return ILQR_OK;
+        };
+        int rc;
+        if ((rc = fetch(u_out, mpc_u_log, NU))) return rc;
+        if ((rc = fetch(x_out, mpc_x_log, NX))) return rc;
+        if ((rc = fetch(cost_out, mpc_cost_log, 1))) return rc;
+        return sync();
+    }
+
+    // ---- measurement ----------------------------------------------------------------------
+    int timing_enable(int on) override { timer.on = on != 0; return ILQR_OK; }
+    int timing_reset() override { timer.reset(stream); return ILQR_OK; }
+    int timing_get(double* ms, int64_t* launches) override {
+        timer.resolve(stream);
+        for (int i = 0; i < ILQR_N_PHASES; ++i) {
+            if (ms) ms[i] = timer.ms[i];
+            if (launches) launches[i] = timer.n[i];
+        }
+        return ILQR_OK;
+    }
+    int algorithmic_bytes(double* bytes) override {
+        const double s = sizeof(T), n = NX, m = NU, b = B, Nn = N;
+        // dense, no padding, no symmetry packing
+        bytes[ILQR_PHASE_LINEARIZE] = b * Nn * s * ((n + m) + (2 * n * n + 2 * n * m + n + m + m * m));
+        bytes[ILQR_PHASE_BACKWARD] = b * s * (Nn * (2 * n * n + 3 * n * m + n + 2 * m + m * m) + n * n + n);
+        bytes[ILQR_PHASE_FORWARD] = b * Nn * s * ((n + 2 * m + m * n) + (double)A * (n + m));
+        bytes[ILQR_PHASE_SELECT] = b * (s * (A + 3) + 4 * 4);
+        bytes[ILQR_PHASE_OTHER] = 0;
+        return ILQR_OK;
+    }
+};
+
+}  // namespace ilqr

@@ -1,0 +1,188 @@
+"""GPU parity tests: the HIP hot path (through the C-ABI) against the NumPy oracle on the
+same seeded inputs.  Tolerance (north_star): rtol 1e-5 on K_t, k_t and total cost in the
+fp64 parity mode; the fp32 (reference-precision) mode is checked at a looser, stated
+tolerance because a 200-step fp32 Riccati recursion cannot reach 1e-5 with a different
+operation order."""
+import numpy as np
+import pytest
+
+import ilqr_amd
+from ilqr_amd import _lib, problems
+from oracle import backward_pass, forward_pass, iLQROracle, mpc_closed_loop
+from oracle.build import oracle_from_spec, oracle_from_system
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _specs():
+    return {
+        "pendulum": problems.pendulum_open_loop(N=100),
+        "ua": problems.ua_double_pendulum(N=60),
+        "dp": problems.double_pendulum(N=50),
+    }
+
+
+def _rand_traj(n, m, N, B, seed, scale=1.0):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((B, n, N + 1)) * scale, rng.standard_normal((B, m, N)) * scale
+
+
+@pytest.mark.parametrize("name", ["pendulum", "ua", "dp"])
+@pytest.mark.parametrize("integrator", ["euler", "midpoint", "rk4", "backward_euler"])
+def test_system_callables_match_oracle(name, integrator):
+    """The 12 System callables (system_base.py:223-251) at random points."""
+    p = _specs()[name]
+    dyn = dict(p["dynamics"], integrator=integrator)
+    sysm = ilqr_amd.make_system(dyn, p["cost"])
+    orc = oracle_from_system(sysm)
+    rng = np.random.default_rng(7)
+    n, m = sysm.n_x, sysm.n_u
+    xs = rng.standard_normal((5, n)) * 1.5
+    us = rng.standard_normal((5, m)) * 2.0
+    for x, u in zip(xs, us):
+        for fn in ("f_fcn", "f_x_fcn", "f_u_fcn", "l_fcn", "l_x_fcn", "l_u_fcn", "l_xx_fcn", "l_uu_fcn", "l_ux_fcn"):
+            got, want = getattr(sysm, fn)(x, u), getattr(orc, fn)(x, u)
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11, err_msg=f"{name} {integrator} {fn}")
+        for fn in ("l_f_fcn", "l_f_x_fcn", "l_f_xx_fcn"):
+            np.testing.assert_allclose(getattr(sysm, fn)(x), getattr(orc, fn)(x), rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["pendulum", "ua", "dp"])
+def test_backward_pass_matches_oracle(name):
+    """K_t, k_t of one backward sweep around a random trajectory: rtol 1e-5 (fp64)."""
+    p = _specs()[name]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    N, B = p["N"], 5
+    X, U = _rand_traj(sysm.n_x, sysm.n_u, N, B, seed=11, scale=0.7)
+    s = ilqr_amd.iLQR(sysm, None, X[:, :, 0], U, N=N, verbose=False)
+    uff, K = s.backward_pass(X, U)
+    for b in range(B):
+        uff_o, K_o = backward_pass(orc, X[b], U[b])
+        np.testing.assert_allclose(K[b], K_o, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(uff[b], uff_o, rtol=RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", ["pendulum", "ua", "dp"])
+@pytest.mark.parametrize("alpha", [0.0, 1.0, 0.25])
+def test_forward_pass_matches_oracle(name, alpha):
+    p = _specs()[name]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    N, B = p["N"], 4
+    n, m = sysm.n_x, sysm.n_u
+    rng = np.random.default_rng(5)
+    X, U = _rand_traj(n, m, N, B, seed=3, scale=0.3)
+    uff = rng.standard_normal((B, m, N)) * 0.1
+    K = rng.standard_normal((B, N, m, n)) * 0.1
+    x0 = rng.standard_normal((B, n)) * 0.3
+    s = ilqr_amd.iLQR(sysm, None, x0, U, N=N, verbose=False)
+    Xn, Un, c = s.forward_pass(x0, alpha, X, U, uff, K)
+    for b in range(B):
+        Xo, Uo, co = forward_pass(orc, x0[b], alpha, X[b], U[b], uff[b], K[b])
+        np.testing.assert_allclose(c[b], co, rtol=RTOL)
+        np.testing.assert_allclose(Xn[b], Xo, rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(Un[b], Uo, rtol=1e-6, atol=1e-8)
+
+
+def test_linearize_tensor_matches_oracle():
+    """ILQR_LIN (the materialised expansion the backward kernel streams) element by element."""
+    p = _specs()["ua"]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    N, B = 12, 3
+    x0, U = problems.ua_batch(B, seed=2, restarts=True, N=N)
+    s = ilqr_amd.iLQR(sysm, None, x0, U, N=N, verbose=False)
+    h = s.handle
+    h.initial_rollout()
+    h.linearize()
+    lin = h.get(_lib.LIN)
+    X, Uc = h.get(_lib.X), h.get(_lib.U)
+    for b in range(B):
+        for t in range(N):
+            x, u = X[b, :, t], Uc[b, :, t]
+            want = np.concatenate([orc.f_x(x, u).ravel(), orc.f_u(x, u).ravel(), orc.l_x(x, u), orc.l_u(x, u),
+                                   orc.l_xx(x, u).ravel(), orc.l_ux(x, u).ravel(), orc.l_uu(x, u).ravel()])
+            np.testing.assert_allclose(lin[b, t], want, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,maxiter", [("pendulum", 20), ("ua", 8), ("dp", 8)])
+def test_full_solve_matches_oracle(name, maxiter):
+    """optimize_trajectory (iLQR_class.py:250-313) for a small batch: same accepted alphas,
+    same iteration counts, same status, cost / K / k at rtol 1e-5."""
+    p = _specs()[name]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    N, B = p["N"], 3
+    n, m = sysm.n_x, sysm.n_u
+    rng = np.random.default_rng(21)
+    x0 = np.asarray(p["x0"])[None, :] + rng.standard_normal((B, n)) * 0.1
+    U0 = rng.standard_normal((B, m, N)) * 0.1
+    s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=p["tol"], maxiter=maxiter, verbose=False)
+    X, U, cost = s.optimize_trajectory()
+    K, uff = s.K, s.U_ff
+    for b in range(B):
+        o = iLQROracle(orc, N=N, x_0=x0[b], U_init=U0[b], tol=p["tol"], maxiter=maxiter)
+        Xo, Uo, co = o.optimize_trajectory()
+        assert s.status[b] == o.status
+        assert int(s.iterations[b]) == o.iterations
+        np.testing.assert_allclose(cost[b], co, rtol=RTOL)
+        np.testing.assert_allclose(K[b], o.K, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(uff[b], o.U_ff, rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(X[b], Xo, rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(U[b], Uo, rtol=1e-5, atol=1e-7)
+
+
+def test_unbatched_api_matches_reference_layouts():
+    """B = 1 drop-in surface: shapes (n, N+1), (m, N), (N, m, n) and block_until_ready()."""
+    p = problems.pendulum_open_loop(integrator="rk4", N=50)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    s = ilqr_amd.iLQR(sysm, 0.5, p["x0"], np.zeros((1, 50)), tol=1e-5, maxiter=5, verbose=False)
+    assert s.N == 50
+    Xw = np.zeros_like(s.X)
+    Uw = np.zeros_like(s.U)
+    uff, K = s.backward_pass(Xw, Uw)
+    uff.block_until_ready()
+    assert uff.shape == (1, 50) and K.shape == (50, 1, 2)
+    Xn, Un, c = s.forward_pass(s.x_0, 0.0, Xw, Uw, uff * 0, K * 0)
+    assert Xn.shape == (2, 51) and Un.shape == (1, 50) and np.ndim(c) == 0
+    X, U, cost = s.optimize_trajectory()
+    assert X.shape == (2, 51) and U.shape == (1, 50)
+    o = iLQROracle(oracle_from_system(sysm), N=50, x_0=p["x0"], U_init=np.zeros((1, 50)), tol=1e-5, maxiter=5)
+    _, _, co = o.optimize_trajectory()
+    np.testing.assert_allclose(cost, co, rtol=RTOL)
+
+
+def test_mpc_closed_loop_matches_oracle():
+    """run_iLQR_MPC.py:116-143 incl. the state carried between solves."""
+    p = problems.pendulum_mpc(N=40)
+    n_sim = 6
+    st = ilqr_amd.mpc_init(p["dynamics"], p["cost"], p["x0"], p["U_init"], plant_integrator=p["plant_integrator"],
+                           N=40, tol=p["tol"], maxiter=p["maxiter"])
+    U_sim, X_sim, costs = st.solver.mpc_run(n_sim)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    plant = oracle_from_spec(p["dynamics"], p["cost"], integrator=p["plant_integrator"])
+    o = iLQROracle(orc, N=40, x_0=p["x0"], U_init=p["U_init"], tol=p["tol"], maxiter=p["maxiter"])
+    Xo, Uo, co = mpc_closed_loop(o, plant, p["x0"], p["U_init"], n_sim)
+    np.testing.assert_allclose(U_sim, Uo.T, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(X_sim, Xo[:, 1:].T, rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(costs, co, rtol=RTOL)
+
+
+def test_fp32_mode_error_is_bounded():
+    """Reference precision (JAX default f32): stated tolerance 2e-3 on K, k; 1e-4 on cost."""
+    p = _specs()["ua"]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], dtype=np.float32)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    N, B = p["N"], 4
+    X, U = _rand_traj(4, 1, N, B, seed=11, scale=0.5)
+    s = ilqr_amd.iLQR(sysm, None, X[:, :, 0], U, N=N, verbose=False)
+    uff, K = s.backward_pass(X, U)
+    assert uff.dtype == np.float32
+    for b in range(B):
+        uff_o, K_o = backward_pass(orc, X[b].astype(np.float32).astype(np.float64),
+                                   U[b].astype(np.float32).astype(np.float64))
+        np.testing.assert_allclose(K[b], K_o, rtol=2e-3, atol=2e-3 * np.abs(K_o).max())
+        np.testing.assert_allclose(uff[b], uff_o, rtol=2e-3, atol=2e-3 * np.abs(uff_o).max())
