@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- iLQR iterations/sec of the batched hot path on N x MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--dtype f64|f32] [--batch B]
+
+A "step" is one iLQR iteration over the whole batch: linearise every (b, t), backward
+Riccati sweep, rollouts of every trial alpha of the backtracking line search, accept.
+Workload (BASELINE.json configs[2], "c3"): under-actuated double pendulum swing-up,
+n=4 m=1, N=200, rk4, batch 4096 trajectories PER GPU, 8 parallel alphas (+ the 2 remaining
+reference trials as a second pass), parameters of run_iLQR_UA_MPC.py:17-67, seeded random
+initial states.  Throughput mode (ILQR_FLAG_KEEP_ITERATING): no trajectory ever leaves the
+loop, so every step does the full batch's work.  Inputs are resident in HBM before the
+timed region.  For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL): each
+rank owns an independent shard (weak scaling, no data-path collective); the only exchange
+is the per-step all-reduce of {min cost, max |dcost|, #active, #converged}.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the
+backward-sweep kernel (HIP events on the kernel's own stream) and `cpu_baseline` (the C
+restatement of the reference algorithm, oracle/c, timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def cpu_baseline(p, n_alpha, dtype, budget_s=12.0):
+    """The oracle's C restatement of the reference loop (sequential backtracking, one trajectory
+    per call) on the host cores: a bounded sample of the same workload, all cores via fork."""
+    import multiprocessing as mp
+    from oracle.c_oracle import COracle, build
+    from ilqr_amd import problems
+    build()
+    cores = os.cpu_count() or 1
+    iters = 10
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    # calibrate on one trajectory, then size the sample to the budget
+    x0, U0 = problems.ua_batch(max(cores * 4, 64), seed=0, restarts=False, N=p["N"])
+    co = COracle(p["dynamics"], p["cost"], dtype=np_dt)
+    t0 = time.perf_counter()
+    co.solve(x0[0], U0[0], fixed_iters=iters)
+    t1 = time.perf_counter() - t0
+    per_core = max(1, min(len(x0) // cores, int(budget_s / max(t1, 1e-6))))
+    n_traj = per_core * cores
+
+    def work(rank, q):
+        c = COracle(p["dynamics"], p["cost"], dtype=np_dt)
+        for i in range(rank * per_core, (rank + 1) * per_core):
+            c.solve(x0[i % len(x0)], U0[i % len(x0)], fixed_iters=iters)
+        q.put(rank)
+
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=work, args=(r, q)) for r in range(cores)]
+    t0 = time.perf_counter()
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join()
+    wall = time.perf_counter() - t0
+    return {"value": n_traj * iters / wall, "unit": "iLQR iterations/sec", "cores": cores, "kind": "port",
+            "single_core_value": iters / t1,
+            "sample": f"{n_traj} trajectories x {iters} iterations of the same problem (C restatement of the "
+                      f"reference loop, {dtype}, sequential backtracking), {cores} processes"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--n-alpha", type=int, default=8)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-phase-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ilqr_amd
+    from ilqr_amd import _lib, problems
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}` "
+                         f"(WORLD_SIZE is {world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL
+
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    p = problems.ua_double_pendulum(integrator="rk4", N=200)
+    B, N = args.batch, p["N"]
+    x0, U0 = problems.ua_batch(B, seed=1000 + rank, restarts=False, N=N)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
+    # launch on torch's current stream so barriers / synchronize / events see the kernels
+    stream = torch.cuda.current_stream().cuda_stream
+    h = sysm.make_handle(horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=1 << 30,
+                         device=local_rank, flags=_lib.FLAG_KEEP_ITERATING, stream=stream)
+    h.set_problem(x0, U0)       # uploads: inputs are HBM-resident from here on
+    h.initial_rollout()
+    stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+
+    def step():
+        h.iterate(1)
+        if world > 1:
+            # the path's only inter-GPU exchange: best cost / convergence
+            h.status_reduce(stats.data_ptr())
+            neg = torch.stack([-stats[0], stats[1]])
+            dist.all_reduce(neg, op=dist.ReduceOp.MAX)
+            dist.all_reduce(stats[2:], op=dist.ReduceOp.SUM)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_phase_timing:
+        h.timing_enable(True)
+        h.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    wall = time.perf_counter() - t0
+    phases = h.timing_get() if not args.no_phase_timing else None
+    h.timing_enable(False)
+
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+    cost = h.get(_lib.COST)
+    finite = bool(np.isfinite(cost).all())
+
+    if rank == 0:
+        value = world * B * args.steps / wall
+        out = {
+            "metric": "iLQR iterations/sec (batch=4096, T=200, n=4 m=1); backward-pass HBM GB/s",
+            "value": value, "unit": "iLQR iterations/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "c3: under-actuated double pendulum swing-up (run_iLQR_UA_MPC.py params), "
+                                   "n=4 m=1 N=200 rk4, batch 4096 trajectories per GPU, 8 parallel line-search "
+                                   "alphas + 2 in a second pass (10 reference trials), fixed iterations",
+                       "batch_per_gpu": B, "horizon": N, "n_alpha": args.n_alpha, "n_trials": 10,
+                       "sharding": f"{world} independent shards, scalar all-reduce per step" if world > 1
+                       else "single shard"},
+            "all_costs_finite": finite,
+        }
+        if phases is not None:
+            ab = h.algorithmic_bytes()
+            ms, n = phases["backward"]
+            avg_s = ms / max(n, 1) * 1e-3
+            achieved = ab["backward"] / avg_s / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": "backward Riccati sweep", "achieved": achieved,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": None, "algorithmic_bytes_per_launch": ab["backward"],
+                               "avg_launch_us": avg_s * 1e6, "launches": n}
+            out["phases_us_per_step"] = {k: 1e3 * v[0] / args.steps for k, v in phases.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p, args.n_alpha, args.dtype)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

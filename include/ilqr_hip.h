@@ -214,6 +214,13 @@ int ilqr_mpc_reset(ilqr_handle h, const void* x0, const void* U_init);
  * u_out [n_steps][B][n_u], x_out [n_steps][B][n_x] (state after each step), cost_out [n_steps][B]; may be NULL */
 int ilqr_mpc_run(ilqr_handle h, int n_steps, void* u_out, void* x_out, void* cost_out);
 
+/* ---- multi-GPU hook -------------------------------------------
+ * Writes 4 doubles to DEVICE memory `dev_out4` on the handle's stream:
+ *   { min cost, max |cost - cost_prev|, #trajectories still active, #converged }
+ * of this handle's shard.  The host side all-reduces them over RCCL (MIN / MAX / SUM / SUM);
+ * it is the only inter-GPU exchange of the path -- trajectories never interact. */
+int ilqr_status_reduce(ilqr_handle h, void* dev_out4);
+
 /* ---- measurement ------------------------------------------------------------ */
 int ilqr_timing_enable(ilqr_handle h, int on);
 int ilqr_timing_reset(ilqr_handle h);

@@ -37,7 +37,7 @@ SYMBOLS = (
     "ilqr_create", "ilqr_destroy", "ilqr_sync", "ilqr_set_problem", "ilqr_set", "ilqr_get",
     "ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_forward", "ilqr_select", "ilqr_iterate",
     "ilqr_solve", "ilqr_backward_pass", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
-    "ilqr_mpc_run", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
+    "ilqr_mpc_run", "ilqr_status_reduce", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
 )
 
 
@@ -110,6 +110,7 @@ def load():
     lib.ilqr_eval_points.argtypes = [vp, ci, ci] + [vp] * 14
     lib.ilqr_mpc_reset.argtypes = [vp, vp, vp]
     lib.ilqr_mpc_run.argtypes = [vp, ci, vp, vp, vp]
+    lib.ilqr_status_reduce.argtypes = [vp, vp]
     lib.ilqr_timing_enable.argtypes = [vp, ci]
     lib.ilqr_timing_get.argtypes = [vp, C.POINTER(cd), C.POINTER(C.c_int64)]
     lib.ilqr_algorithmic_bytes.argtypes = [vp, C.POINTER(cd)]
@@ -304,6 +305,10 @@ class Handle:
         c = np.empty((n_steps, self.B), dtype=self.np_dtype)
         self._chk(self.lib.ilqr_mpc_run(self.h, int(n_steps), _ptr(u), _ptr(x), _ptr(c)))
         return u, x, c
+
+    def status_reduce(self, dev_ptr):
+        """Write {min cost, max |dcost|, #active, #converged} (4 doubles) to DEVICE memory at dev_ptr."""
+        self._chk(self.lib.ilqr_status_reduce(self.h, C.c_void_p(int(dev_ptr))))
 
     # ---- measurement ------------------------------------------------------------------------------
     def timing_enable(self, on=True):

@@ -483,6 +483,41 @@ __global__ void __launch_bounds__(256) select_kernel(KArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------
+// status_reduce: shard-local {min cost, max |dcost|, #active, #converged} as 4 doubles, the
+// operand of the only inter-GPU collective of the path (one block; B is a few thousand).
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) status_reduce_kernel(const T* cost, const T* cost_prev, const int* status,
+                                                            int B, double* out4) {
+    __shared__ double s_min[256], s_max[256];
+    __shared__ int s_act[256], s_conv[256];
+    double mn = 1.0 / 0.0, mx = 0.0;
+    int act = 0, conv = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const double c = (double)cost[b];
+        mn = c < mn ? c : mn;
+        const double d = fabs(c - (double)cost_prev[b]);
+        mx = d > mx ? d : mx;
+        const int st = status[b] & 0xff;
+        act += st == ILQR_TRAJ_ACTIVE;
+        conv += st == ILQR_TRAJ_CONVERGED;
+    }
+    s_min[threadIdx.x] = mn; s_max[threadIdx.x] = mx; s_act[threadIdx.x] = act; s_conv[threadIdx.x] = conv;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) {
+            const int o = threadIdx.x + w;
+            s_min[threadIdx.x] = s_min[o] < s_min[threadIdx.x] ? s_min[o] : s_min[threadIdx.x];
+            s_max[threadIdx.x] = s_max[o] > s_max[threadIdx.x] ? s_max[o] : s_max[threadIdx.x];
+            s_act[threadIdx.x] += s_act[o];
+            s_conv[threadIdx.x] += s_conv[o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out4[0] = s_min[0]; out4[1] = s_max[0]; out4[2] = s_act[0]; out4[3] = s_conv[0]; }
+}
+
+// ---------------------------------------------------------------------------
 // eval_points: the 12 System callables (system_base.py:223-251) at arbitrary
 // points, dense row-major outputs; NULL outputs are skipped.
 // ---------------------------------------------------------------------------

@@ -41,6 +41,7 @@ struct SolverBase {
     virtual int eval_points(int integ, int npts, const void* x, const void* u, void** outs) = 0;
     virtual int mpc_reset(const void* x0, const void* U) = 0;
     virtual int mpc_run(int n_steps, void* u_out, void* x_out, void* cost_out) = 0;
+    virtual int status_reduce(void* dev_out4) = 0;
     virtual int timing_enable(int on) = 0;
     virtual int timing_reset() = 0;
     virtual int timing_get(double* ms, int64_t* launches) = 0;
@@ -705,6 +706,15 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = fetch(x_out, mpc_x_log, NX))) return rc;
         if ((rc = fetch(cost_out, mpc_cost_log, 1))) return rc;
         return sync();
+    }
+
+    int status_reduce(void* dev_out4) override {
+        if (!dev_out4) { err = "status_reduce: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        timer.begin(ILQR_PHASE_OTHER, stream);
+        hipLaunchKernelGGL(status_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, st.cost, st.cost_prev, st.status, B,
+                           (double*)dev_out4);
+        timer.end(stream);
+        return check_launch();
     }
 
     // ---- measurement ----------------------------------------------------------------------
