@@ -6,9 +6,12 @@
 A "step" is one iLQR iteration over the whole batch: linearise every (b, t), backward
 Riccati sweep, rollouts of every trial alpha of the backtracking line search, accept.
 Workload (BASELINE.json configs[2], "c3"): under-actuated double pendulum swing-up,
-n=4 m=1, N=200, rk4, batch 4096 trajectories PER GPU, 8 parallel alphas (+ the 2 remaining
-reference trials as a second pass), parameters of run_iLQR_UA_MPC.py:17-67, seeded random
-initial states.  Throughput mode (ILQR_FLAG_KEEP_ITERATING): no trajectory ever leaves the
+n=4 m=1, N=200, rk4, batch 4096 trajectories PER GPU, all 10 backtracking trials of the
+reference (alpha = 1, 1/2, ..., 2^-9) rolled out in parallel in ONE pass -- the config's 8
+plus the 2 it would run in a second pass: a second dependent pass costs a full 200-step
+sweep latency whatever its width, so one wider pass is strictly cheaper on this chip
+(--n-alpha 8 reproduces the two-pass form).  Parameters of run_iLQR_UA_MPC.py:17-67, seeded
+random initial states.  Throughput mode (ILQR_FLAG_KEEP_ITERATING): no trajectory ever leaves the
 loop, so every step does the full batch's work.  Inputs are resident in HBM before the
 timed region.  For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL): each
 rank owns an independent shard (weak scaling, no data-path collective); the only exchange
@@ -79,7 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
-    ap.add_argument("--n-alpha", type=int, default=8)
+    ap.add_argument("--n-alpha", type=int, default=10)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true")
@@ -159,8 +162,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "c3: under-actuated double pendulum swing-up (run_iLQR_UA_MPC.py params), "
-                                   "n=4 m=1 N=200 rk4, batch 4096 trajectories per GPU, 8 parallel line-search "
-                                   "alphas + 2 in a second pass (10 reference trials), fixed iterations",
+                                   f"n=4 m=1 N=200 rk4, batch {B} trajectories per GPU, {args.n_alpha} parallel "
+                                   "line-search alphas per pass covering the 10 reference trials, fixed iterations",
                        "batch_per_gpu": B, "horizon": N, "n_alpha": args.n_alpha, "n_trials": 10,
                        "sharding": f"{world} independent shards, scalar all-reduce per step" if world > 1
                        else "single shard"},

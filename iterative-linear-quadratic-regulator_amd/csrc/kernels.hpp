@@ -2,8 +2,10 @@
 //
 // HBM data layout ("batch innermost", scalar type T):
 //   X    [n_slots][N+1][n_x][B]      U    [n_slots][N][n_u][B]
-//   K    [N][n_u][n_x][B]            kff  [N][n_u][B]           (U_ff of the reference)
-//   lin  [N][E][B]   E = 2n^2+2nm+n+m+m^2, per step f_x f_u l_x l_u l_xx l_ux l_uu
+//   gains [N][B][R]  one record per (t, b): K_t (n_u*n_x, row-major) then k_t (n_u) = U_ff of the
+//                    reference, R = n_u*n_x + n_u rounded up to a multiple of 4 scalars (16-B loads)
+//   lin  generic:    [N][E][B]   E = 2n^2+2nm+n+m+m^2, per step f_x f_u l_x l_u l_xx l_ux l_uu
+//        n=4, m=1:   [N][B][48]  one 192-B (f32) tile per (t, b), packed for the 16-lane sweep below
 //   term [n + n^2][B]                (l_f_x, l_f_xx)
 //   costs [n_alpha][B]   cost, cost_prev, alpha_taken [B]   status, iters, accepted, cur_slot [B]
 // A trajectory b is a column of every tensor, so 64 consecutive trajectories are one
@@ -29,13 +31,19 @@ template <typename T> struct KArgs {
     T dt, tol, mu;
     T alphas[kMaxAlpha];
     T* X; T* U; int* cur_slot;
-    T* K; T* kff; T* lin; T* term; T* x0;
+    T* gains; T* lin; T* term; T* x0;
     T* costs; T* cost; T* cost_prev; T* alpha_taken;
     int* status; int* iters; int* accepted; int* counters;
     const T* params;
 };
 
+constexpr int gain_record(int nx, int nu) { return ((nu * nx + nu) + 3) / 4 * 4; }
+
 ILQR_DEV bool traj_active(int status) { return (status & 0xff) == ILQR_TRAJ_ACTIVE; }
+
+}  // namespace ilqr
+#include "backward_tile16.hpp"
+namespace ilqr {
 
 // ---------------------------------------------------------------------------
 // linearize: one lane per (b, t) point, t in [0, N]; t == N is the terminal
@@ -43,7 +51,7 @@ ILQR_DEV bool traj_active(int status) { return (status & 0xff) == ILQR_TRAJ_ACTI
 // (iLQR_class.py:318-331) + l_f_x / l_f_xx (:136-138), hoisted out of the
 // sequential scan because it does not depend on the carry.
 // ---------------------------------------------------------------------------
-template <typename T, typename Dyn>
+template <typename T, typename Dyn, bool TILE16, int INTEG>
 __global__ void __launch_bounds__(256) linearize_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
@@ -73,7 +81,37 @@ __global__ void __launch_bounds__(256) linearize_kernel(KArgs<T> a) {
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = Up[(size_t)i * B];
     T xn[NX], fx[NX][NX], fu[NX][NU];
-    Stepper<T, Dyn>::step_jac(a.integ, p, a.dt, x, u, xn, fx, fu);
+    Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);  // integrator folded at compile time
+    if constexpr (TILE16) {
+        // n_x = 4, n_u = 1: pack the 46 scalars into the 48-scalar tile of backward_tile16.hpp
+        static_assert(NX == 4 && NU == 1, "tile packing is for n_x = 4, n_u = 1");
+        using V4 = typename Vec4<T>::type;
+        T gx[NX], gu1[NU];
+        Cost<T, Dyn>::l_x(p, a.dt, x, gx);
+        Cost<T, Dyn>::l_u(p, a.dt, u, gu1);
+        V4* out4 = reinterpret_cast<V4*>(a.lin + ((size_t)t * B + b) * kTile16);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            V4 v;
+            v.x = fx[(c + 0) & 3][c]; v.y = fx[(c + 1) & 3][c]; v.z = fx[(c + 2) & 3][c]; v.w = fx[(c + 3) & 3][c];
+            out4[c] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            V4 v;
+            v.x = p[PL::QS + 4 * i + 0] * a.dt; v.y = p[PL::QS + 4 * i + 1] * a.dt;
+            v.z = p[PL::QS + 4 * i + 2] * a.dt; v.w = p[PL::QS + 4 * i + 3] * a.dt;
+            out4[4 + i] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            V4 v;
+            v.x = fu[j][0]; v.y = gx[j]; v.z = T(0);
+            v.w = (j == 0) ? gu1[0] : ((j == 1) ? p[PL::RS] * a.dt : T(0));
+            out4[8 + j] = v;
+        }
+        return;
+    }
     T* out = a.lin + ((size_t)t * E) * B + b;
     int e = 0;
 #pragma unroll
@@ -344,14 +382,14 @@ __global__ void __launch_bounds__(64) backward_lane_kernel(KArgs<T> a) {
         }
         T K[NU][NX], k[NU];
         all_pd = riccati_step<T, NX, NU>(cur, a.mu, Vx, Vxx, K, k) && all_pd;
-        T* Kp = a.K + ((size_t)t * NU * NX) * B + b;
+        constexpr int R = gain_record(NX, NU);
+        T* rec = a.gains + ((size_t)t * B + b) * R;
 #pragma unroll
         for (int i = 0; i < NU; ++i)
 #pragma unroll
-            for (int j = 0; j < NX; ++j) Kp[(size_t)(i * NX + j) * B] = K[i][j];
-        T* kp = a.kff + ((size_t)t * NU) * B + b;
+            for (int j = 0; j < NX; ++j) rec[i * NX + j] = K[i][j];
 #pragma unroll
-        for (int i = 0; i < NU; ++i) kp[(size_t)i * B] = k[i];
+        for (int i = 0; i < NU; ++i) rec[NU * NX + i] = k[i];
 #pragma unroll
         for (int e = 0; e < E; ++e) cur[e] = nxt[e];
     }
@@ -363,9 +401,10 @@ __global__ void __launch_bounds__(64) backward_lane_kernel(KArgs<T> a) {
 // index.  Replaces iLQR._forward_pass_scan (iLQR_class.py:193-247), all trial
 // alphas of the backtracking loop (:279-302) at once.
 // ---------------------------------------------------------------------------
-template <typename T, typename Dyn>
+template <typename T, typename Dyn, int INTEG>
 __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    constexpr int R = gain_record(NX, NU);
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int ai = blockIdx.y;
     if (b >= a.B) return;
@@ -383,19 +422,36 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     T cost = T(0);
     const T* Xo = a.X + ((size_t)slot * (N + 1) * NX) * B + b;
     const T* Uo = a.U + ((size_t)slot * N * NU) * B + b;
+    const T* G = a.gains + (size_t)b * R;
     T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + b;
     T* Uc = a.U + ((size_t)cslot * N * NU) * B + b;
+    // The per-step inputs (x_old, u_old, K, k) do not depend on the carried state, so step t+1's are
+    // requested before step t's arithmetic starts: their latency hides under one RK4 step.
+    T xo[NX], uo[NU], g[R], xo_n[NX], uo_n[NU], g_n[R];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) xo[i] = Xo[(size_t)i * B];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) uo[j] = Uo[(size_t)j * B];
+#pragma unroll
+    for (int r = 0; r < R; ++r) g[r] = G[r];
     for (int t = 0; t < N; ++t) {
+        const int tn = (t + 1 < N) ? t + 1 : t;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xo_n[i] = Xo[((size_t)tn * NX + i) * B];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) uo_n[j] = Uo[((size_t)tn * NU + j) * B];
+#pragma unroll
+        for (int r = 0; r < R; ++r) g_n[r] = G[(size_t)tn * B * R + r];
         T dx[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = x[i] - Xo[((size_t)t * NX + i) * B];
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             T fb = T(0);
 #pragma unroll
-            for (int i = 0; i < NX; ++i) fb += a.K[((size_t)t * NU * NX + j * NX + i) * B + b] * dx[i];
+            for (int i = 0; i < NX; ++i) fb += g[j * NX + i] * dx[i];
             // u = u_old + alpha * k + K (x - x_old)   (iLQR_class.py:181-182)
-            u[j] = Uo[((size_t)t * NU + j) * B] + alpha * a.kff[((size_t)t * NU + j) * B + b] + fb;
+            u[j] = uo[j] + alpha * g[NU * NX + j] + fb;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) Xc[((size_t)t * NX + i) * B] = x[i];
@@ -403,9 +459,13 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
         for (int j = 0; j < NU; ++j) Uc[((size_t)t * NU + j) * B] = u[j];
         cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
         T xn[NX];
-        Stepper<T, Dyn>::step(a.integ, p, a.dt, x, u, xn);
+        Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);  // integrator folded at compile time
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        for (int i = 0; i < NX; ++i) { x[i] = xn[i]; xo[i] = xo_n[i]; }
+#pragma unroll
+        for (int j = 0; j < NU; ++j) uo[j] = uo_n[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) g[r] = g_n[r];
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
@@ -679,6 +739,45 @@ __global__ void gather_tc_kernel(T* dense, const T* dev, int B, int C, int Tn) {
     const int c = (int)((idx / B) % C);
     const int t = (int)(idx / ((size_t)B * C));
     dense[((size_t)b * Tn + t) * C + c] = dev[((size_t)t * C + c) * B + b];
+}
+
+
+// gains[t][b][R] <-> the reference layouts K [B][N][n_u][n_x], U_ff [B][n_u][N]
+template <typename T>
+__global__ void gains_scatter_K_kernel(const T* denseK, T* gains, int B, int N, int MN, int R) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * MN) return;
+    const int c = (int)(idx % MN);
+    const int t = (int)((idx / MN) % N);
+    const int b = (int)(idx / ((size_t)MN * N));
+    gains[((size_t)t * B + b) * R + c] = denseK[idx];
+}
+template <typename T>
+__global__ void gains_gather_K_kernel(T* denseK, const T* gains, int B, int N, int MN, int R) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * MN) return;
+    const int c = (int)(idx % MN);
+    const int t = (int)((idx / MN) % N);
+    const int b = (int)(idx / ((size_t)MN * N));
+    denseK[idx] = gains[((size_t)t * B + b) * R + c];
+}
+template <typename T>
+__global__ void gains_scatter_k_kernel(const T* denseUff, T* gains, int B, int N, int M, int MN, int R) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * M) return;
+    const int t = (int)(idx % N);
+    const int j = (int)((idx / N) % M);
+    const int b = (int)(idx / ((size_t)M * N));
+    gains[((size_t)t * B + b) * R + MN + j] = denseUff[idx];
+}
+template <typename T>
+__global__ void gains_gather_k_kernel(T* denseUff, const T* gains, int B, int N, int M, int MN, int R) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * M) return;
+    const int t = (int)(idx % N);
+    const int j = (int)((idx / N) % M);
+    const int b = (int)(idx / ((size_t)M * N));
+    denseUff[idx] = gains[((size_t)t * B + b) * R + MN + j];
 }
 
 }  // namespace ilqr

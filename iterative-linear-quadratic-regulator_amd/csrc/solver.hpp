@@ -66,28 +66,56 @@ bool supported_f64(int system, int n_x, int n_u);
     } while (0)
 
 template <typename T> struct Ops {
-    void (*linearize)(const KArgs<T>&, hipStream_t) = nullptr;
+    void (*linearize[5])(const KArgs<T>&, hipStream_t) = {};  // indexed by ilqr_integrator
     void (*backward)(const KArgs<T>&, hipStream_t) = nullptr;
-    void (*forward)(const KArgs<T>&, hipStream_t) = nullptr;
+    void (*forward[5])(const KArgs<T>&, hipStream_t) = {};
     void (*eval)(const EvalArgs<T>&, hipStream_t) = nullptr;
     void (*mpc_advance)(const MpcArgs<T>&, hipStream_t) = nullptr;
     int n_dev_params = 0;
     int n_sys_dev = 0;
+    int lin_stride = 0;   // scalars per (b, t) in the expansion buffer
+    bool tile16 = false;  // expansion packed as 48-scalar tiles (n_x = 4, n_u = 1)
 };
+
+// linearize / forward are compiled once per integrator so the integrator switch folds away and each
+// variant gets its own register allocation (the RK4 rollout must not pay for the backward-Euler LU).
+template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_ops(Ops<T>& o) {
+    constexpr bool SMALL = Dyn::NX <= 4;
+    // n_x > 4 only has the closed-form integrators: fold the others onto euler so nothing big is compiled
+    constexpr int I = (SMALL || INTEG == ILQR_INT_DISCRETE) ? INTEG : ILQR_INT_EULER;
+    o.linearize[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
+        const size_t total = (size_t)a.B * (a.N + 1);
+        hipLaunchKernelGGL((linearize_kernel<T, Dyn, TILE, I>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    };
+    o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((forward_kernel<T, Dyn, I>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+    };
+}
 
 template <typename T, typename Dyn> Ops<T> make_ops() {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     Ops<T> o;
-    o.linearize = [](const KArgs<T>& a, hipStream_t s) {
-        const size_t total = (size_t)a.B * (a.N + 1);
-        hipLaunchKernelGGL((linearize_kernel<T, Dyn>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-    };
-    o.backward = [](const KArgs<T>& a, hipStream_t s) {
-        hipLaunchKernelGGL((backward_lane_kernel<T, NX, NU>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
-    };
-    o.forward = [](const KArgs<T>& a, hipStream_t s) {
-        hipLaunchKernelGGL((forward_kernel<T, Dyn>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
-    };
+    constexpr bool TILE = (NX == 4 && NU == 1);
+    o.tile16 = TILE;
+    o.lin_stride = TILE ? kTile16 : (2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU);
+    set_integrator_ops<T, Dyn, TILE, 0>(o);
+    set_integrator_ops<T, Dyn, TILE, 1>(o);
+    set_integrator_ops<T, Dyn, TILE, 2>(o);
+    set_integrator_ops<T, Dyn, TILE, 3>(o);
+    set_integrator_ops<T, Dyn, TILE, 4>(o);
+    if constexpr (TILE) {
+        // one wave = 4 trajectories x 16 lanes; 1024 single-wave workgroups at B = 4096 = one per SIMD
+        o.backward = [](const KArgs<T>& a, hipStream_t s) {
+            if (a.mu != T(0))
+                hipLaunchKernelGGL((backward_tile16_kernel<T, true>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+            else
+                hipLaunchKernelGGL((backward_tile16_kernel<T, false>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+        };
+    } else {
+        o.backward = [](const KArgs<T>& a, hipStream_t s) {
+            hipLaunchKernelGGL((backward_lane_kernel<T, NX, NU>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+        };
+    }
     o.eval = [](const EvalArgs<T>& a, hipStream_t s) {
         hipLaunchKernelGGL((eval_points_kernel<T, Dyn>), dim3((a.npts + 63) / 64), dim3(64), 0, s, a);
     };
@@ -193,14 +221,14 @@ struct PhaseTimer {
 // pure functional calls (backward_pass / forward_pass) so they never disturb the solver.
 template <typename T> struct DeviceState {
     int n_slots = 0;
-    T *X = nullptr, *U = nullptr, *K = nullptr, *kff = nullptr, *lin = nullptr, *term = nullptr, *x0 = nullptr;
+    T *X = nullptr, *U = nullptr, *gains = nullptr, *lin = nullptr, *term = nullptr, *x0 = nullptr;
     T *costs = nullptr, *cost = nullptr, *cost_prev = nullptr, *alpha_taken = nullptr;
     int *cur_slot = nullptr, *status = nullptr, *iters = nullptr, *accepted = nullptr, *counters = nullptr;
 };
 
 template <typename T> class SolverT : public SolverBase {
   public:
-    int B, N, NX, NU, E, A;
+    int B, N, NX, NU, E, A, R;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     Ops<T> ops;
@@ -232,7 +260,7 @@ template <typename T> class SolverT : public SolverBase {
     }
 
     static void free_state(DeviceState<T>& s) {
-        hipFree(s.X); hipFree(s.U); hipFree(s.K); hipFree(s.kff); hipFree(s.lin); hipFree(s.term); hipFree(s.x0);
+        hipFree(s.X); hipFree(s.U); hipFree(s.gains); hipFree(s.lin); hipFree(s.term); hipFree(s.x0);
         hipFree(s.costs); hipFree(s.cost); hipFree(s.cost_prev); hipFree(s.alpha_taken);
         hipFree(s.cur_slot); hipFree(s.status); hipFree(s.iters); hipFree(s.accepted); hipFree(s.counters);
         s = DeviceState<T>();
@@ -248,9 +276,8 @@ template <typename T> class SolverT : public SolverBase {
         };
         ILQR_HIPCHK(al(&s.X, (size_t)n_slots * (N + 1) * NX * b));
         ILQR_HIPCHK(al(&s.U, (size_t)n_slots * N * NU * b));
-        ILQR_HIPCHK(al(&s.K, (size_t)N * NU * NX * b));
-        ILQR_HIPCHK(al(&s.kff, (size_t)N * NU * b));
-        ILQR_HIPCHK(al(&s.lin, (size_t)N * E * b));
+        ILQR_HIPCHK(al(&s.gains, (size_t)N * R * b));
+        ILQR_HIPCHK(al(&s.lin, (size_t)N * ops.lin_stride * b));
         ILQR_HIPCHK(al(&s.term, (size_t)(NX + NX * NX) * b));
         ILQR_HIPCHK(al(&s.x0, (size_t)NX * b));
         ILQR_HIPCHK(al(&s.costs, (size_t)kMaxAlpha * b));
@@ -269,6 +296,7 @@ template <typename T> class SolverT : public SolverBase {
         cfg = c;
         B = c.batch; N = c.horizon; NX = c.n_x; NU = c.n_u; A = c.n_alpha;
         E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+        R = gain_record(NX, NU);
         if (!find_ops<T>(c.system, NX, NU, &ops)) {
             err = "no kernels compiled for this (system, n_x, n_u, dtype)";
             return ILQR_ERR_UNSUPPORTED;
@@ -307,7 +335,7 @@ template <typename T> class SolverT : public SolverBase {
         KArgs<T> a{};
         a.B = B; a.N = N; a.n_slots = s.n_slots; a.integ = cfg.integrator; a.maxiter = cfg.maxiter; a.flags = cfg.flags;
         a.dt = (T)cfg.dt; a.tol = (T)cfg.tol; a.mu = (T)cfg.mu;
-        a.X = s.X; a.U = s.U; a.cur_slot = s.cur_slot; a.K = s.K; a.kff = s.kff; a.lin = s.lin; a.term = s.term;
+        a.X = s.X; a.U = s.U; a.cur_slot = s.cur_slot; a.gains = s.gains; a.lin = s.lin; a.term = s.term;
         a.x0 = s.x0; a.costs = s.costs; a.cost = s.cost; a.cost_prev = s.cost_prev; a.alpha_taken = s.alpha_taken;
         a.status = s.status; a.iters = s.iters; a.accepted = s.accepted; a.counters = s.counters; a.params = params;
         return a;
@@ -355,12 +383,48 @@ template <typename T> class SolverT : public SolverBase {
         return check_launch();
     }
 
+    int up_gain_K(const void* host, T* gains) {
+        const size_t n = (size_t)B * N * NU * NX;
+        ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(gains_scatter_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU * NX, R);
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+    int down_gain_K(void* host, const T* gains) {
+        const size_t n = (size_t)B * N * NU * NX;
+        hipLaunchKernelGGL(gains_gather_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU * NX, R);
+        ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+    int up_gain_k(const void* host, T* gains) {
+        const size_t n = (size_t)B * N * NU;
+        ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(gains_scatter_k_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU, NU * NX, R);
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+    int down_gain_k(void* host, const T* gains) {
+        const size_t n = (size_t)B * N * NU;
+        hipLaunchKernelGGL(gains_gather_k_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU, NU * NX, R);
+        ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+    int down_lin(void* host, const T* lin) {
+        if (!ops.tile16) return down_tc(host, lin, E, N);
+        const size_t n = (size_t)B * N * E;
+        hipLaunchKernelGGL(tile16_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
+        ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+
     int zero_solver_state(DeviceState<T>& s) {
         const size_t b = B;
         ILQR_HIPCHK(hipMemsetAsync(s.X, 0, (size_t)s.n_slots * (N + 1) * NX * b * sizeof(T), stream));
         ILQR_HIPCHK(hipMemsetAsync(s.U, 0, (size_t)s.n_slots * N * NU * b * sizeof(T), stream));
-        ILQR_HIPCHK(hipMemsetAsync(s.K, 0, (size_t)N * NU * NX * b * sizeof(T), stream));
-        ILQR_HIPCHK(hipMemsetAsync(s.kff, 0, (size_t)N * NU * b * sizeof(T), stream));
+        ILQR_HIPCHK(hipMemsetAsync(s.gains, 0, (size_t)N * R * b * sizeof(T), stream));
         ILQR_HIPCHK(hipMemsetAsync(s.cur_slot, 0, b * sizeof(int), stream));
         ILQR_HIPCHK(hipMemsetAsync(s.status, 0, b * sizeof(int), stream));
         ILQR_HIPCHK(hipMemsetAsync(s.iters, 0, b * sizeof(int), stream));
@@ -405,8 +469,8 @@ template <typename T> class SolverT : public SolverBase {
         switch (field) {
             case ILQR_X: return up_ct(src, st.X, st.cur_slot, NX, N + 1);
             case ILQR_U: return up_ct(src, st.U, st.cur_slot, NU, N);
-            case ILQR_UFF: return up_ct(src, st.kff, nullptr, NU, N);
-            case ILQR_K: return up_tc(src, st.K, NU * NX, N);
+            case ILQR_UFF: return up_gain_k(src, st.gains);
+            case ILQR_K: return up_gain_K(src, st.gains);
             case ILQR_X0: return up_tc(src, st.x0, NX, 1);
             case ILQR_PLANT_X: return up_tc(src, plant_x, NX, 1);
             default: err = "set: field is read-only"; return ILQR_ERR_INVALID_ARG;
@@ -420,11 +484,11 @@ template <typename T> class SolverT : public SolverBase {
         switch (field) {
             case ILQR_X: return down_ct(dst, st.X, st.cur_slot, NX, N + 1);
             case ILQR_U: return down_ct(dst, st.U, st.cur_slot, NU, N);
-            case ILQR_UFF: return down_ct(dst, st.kff, nullptr, NU, N);
-            case ILQR_K: return down_tc(dst, st.K, NU * NX, N);
+            case ILQR_UFF: return down_gain_k(dst, st.gains);
+            case ILQR_K: return down_gain_K(dst, st.gains);
             case ILQR_X0: return down_tc(dst, st.x0, NX, 1);
             case ILQR_PLANT_X: return down_tc(dst, plant_x, NX, 1);
-            case ILQR_LIN: return down_tc(dst, st.lin, E, N);
+            case ILQR_LIN: return down_lin(dst, st.lin);
             case ILQR_TRIAL_COSTS: return down_tc(dst, st.costs, A, 1);
             case ILQR_COST: ILQR_HIPCHK(hipMemcpyAsync(dst, st.cost, bytes, hipMemcpyDeviceToHost, stream)); return sync();
             case ILQR_ALPHA: ILQR_HIPCHK(hipMemcpyAsync(dst, st.alpha_taken, bytes, hipMemcpyDeviceToHost, stream)); return sync();
@@ -438,7 +502,7 @@ template <typename T> class SolverT : public SolverBase {
     int do_linearize(DeviceState<T>& s) {
         KArgs<T> a = kargs(s);
         timer.begin(ILQR_PHASE_LINEARIZE, stream);
-        ops.linearize(a, stream);
+        ops.linearize[cfg.integrator](a, stream);
         timer.end(stream);
         return check_launch();
     }
@@ -455,7 +519,7 @@ template <typename T> class SolverT : public SolverBase {
         a.n_pass = n;
         for (int i = 0; i < n; ++i) a.alphas[i] = (T)alphas[i];
         timer.begin(ILQR_PHASE_FORWARD, stream);
-        ops.forward(a, stream);
+        ops.forward[cfg.integrator](a, stream);
         timer.end(stream);
         return check_launch();
     }
@@ -594,8 +658,8 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = up_ct(U, fn.U, nullptr, NU, N))) return rc;
         if ((rc = do_linearize(fn))) return rc;
         if ((rc = do_backward(fn))) return rc;
-        if (Uff && (rc = down_ct(Uff, fn.kff, nullptr, NU, N))) return rc;
-        if (K && (rc = down_tc(K, fn.K, NU * NX, N))) return rc;
+        if (Uff && (rc = down_gain_k(Uff, fn.gains))) return rc;
+        if (K && (rc = down_gain_K(K, fn.gains))) return rc;
         return sync();
     }
 
@@ -607,8 +671,8 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = up_tc(x0, fn.x0, NX, 1))) return rc;
         if ((rc = up_ct(X, fn.X, nullptr, NX, N + 1))) return rc;
         if ((rc = up_ct(U, fn.U, nullptr, NU, N))) return rc;
-        if ((rc = up_ct(Uff, fn.kff, nullptr, NU, N))) return rc;
-        if ((rc = up_tc(K, fn.K, NU * NX, N))) return rc;
+        if ((rc = up_gain_k(Uff, fn.gains))) return rc;
+        if ((rc = up_gain_K(K, fn.gains))) return rc;
         if ((rc = do_forward(fn, &alpha, 1))) return rc;
         // the candidate went to slot 1: read it back from there
         T* X1 = fn.X + (size_t)(N + 1) * NX * B;
