@@ -179,6 +179,10 @@ def main():
                                "traffic": None, "algorithmic_bytes_per_launch": ab["backward"],
                                "avg_launch_us": avg_s * 1e6, "launches": n}
             out["phases_us_per_step"] = {k: 1e3 * v[0] / args.steps for k, v in phases.items()}
+        if os.environ.get("ILQR_CLOCK_PROBE"):
+            pr = h.get(_lib.PROBE)
+            out["clock_probe"] = {"backward_cycles": int(pr[0]), "backward_GHz": float(pr[0]) / max(float(pr[1]), 1) * 0.1,
+                                  "forward_cycles": int(pr[2]), "forward_GHz": float(pr[2]) / max(float(pr[3]), 1) * 0.1}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, args.n_alpha, args.dtype)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

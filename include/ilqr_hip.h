@@ -133,7 +133,10 @@ typedef enum ilqr_field {
     ILQR_TRIAL_COSTS = 9, /* [B][n_alpha] costs of the last line-search pass; handle dtype (get only) */
     ILQR_LIN = 10,     /* [B][N][E] raw expansion of the last ilqr_linearize, E = 2n^2+2nm+n+m+m^2, per step:
                           f_x (n*n) f_u (n*m) l_x (n) l_u (m) l_xx (n*n) l_ux (m*n) l_uu (m*m), row-major (get only) */
-    ILQR_PLANT_X = 11  /* [B][n_x] MPC plant state */
+    ILQR_PLANT_X = 11, /* [B][n_x] MPC plant state */
+    ILQR_PROBE = 12    /* 8 x int64 diagnostic clock stamps {shader cycles, 100 MHz ticks} of workgroup 0:
+                          [0,1] backward sweep, [2,3] forward rollout; filled only when the environment variable
+                          ILQR_CLOCK_PROBE is set at ilqr_create (get only) */
 } ilqr_field;
 
 /* Phases timed by ilqr_timing_* (HIP events recorded on the handle's stream). */

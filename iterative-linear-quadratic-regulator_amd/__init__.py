@@ -13,6 +13,7 @@ from .systems import (System, MyPendulum, MyUADoublePendulum, MyDoublePendulum, 
                       MyLinearSystem)
 from .api import solve, SolveResult, MPCState, mpc_init, mpc_step, make_system  # noqa: F401
 from . import problems  # noqa: F401
+from . import dist  # noqa: F401
 
 __all__ = ["iLQR", "horizon_steps", "System", "MyPendulum", "MyUADoublePendulum", "MyDoublePendulum",
            "MyLinearSystem", "solve", "SolveResult", "MPCState", "mpc_init", "mpc_step", "make_system",

@@ -24,7 +24,7 @@ OK, ERR_INVALID_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_STATE = range(
 F32, F64 = 0, 1
 SYS_PENDULUM, SYS_UA_DOUBLE_PENDULUM, SYS_DOUBLE_PENDULUM, SYS_LINEAR = range(4)
 INTEGRATORS = {"euler": 0, "midpoint": 1, "rk4": 2, "backward_euler": 3, "discrete": 4}
-(X, U, K, UFF, X0, COST, STATUS, ITERS, ALPHA, TRIAL_COSTS, LIN, PLANT_X) = range(12)
+(X, U, K, UFF, X0, COST, STATUS, ITERS, ALPHA, TRIAL_COSTS, LIN, PLANT_X, PROBE) = range(13)
 TRAJ_ACTIVE, TRAJ_CONVERGED, TRAJ_LINESEARCH_FAILED, TRAJ_MAXITER = range(4)
 TRAJ_FLAG_NON_PD = 0x100
 FLAG_KEEP_ITERATING = 1
@@ -207,10 +207,10 @@ class Handle:
         B, n, m, N = self.B, self.n_x, self.n_u, self.N
         return {X: (B, n, N + 1), U: (B, m, N), K: (B, N, m, n), UFF: (B, m, N), X0: (B, n), COST: (B,),
                 STATUS: (B,), ITERS: (B,), ALPHA: (B,), TRIAL_COSTS: (B, self.A), LIN: (B, N, self.E),
-                PLANT_X: (B, n)}[field]
+                PLANT_X: (B, n), PROBE: (8,)}[field]
 
     def get(self, field):
-        dt = np.int32 if field in (STATUS, ITERS) else self.np_dtype
+        dt = np.int32 if field in (STATUS, ITERS) else (np.int64 if field == PROBE else self.np_dtype)
         out = np.empty(self.shape(field), dtype=dt)
         self._chk(self.lib.ilqr_get(self.h, field, _ptr(out), out.nbytes))
         return out

@@ -23,6 +23,8 @@
 // Because tile loads never depend on the carried value function, a ring of D tiles per lane is
 // kept in flight in registers (D*5 loads per lane outstanding) so HBM latency hides under compute.
 #pragma once
+#include <type_traits>
+
 #include "dynamics.hpp"
 
 namespace ilqr {
@@ -101,11 +103,49 @@ template <typename T> ILQR_DEV T quad_sum(T v) {
     return v;
 }
 
+// reciprocal = hardware estimate + Newton steps (1 for float, 2 for double): ~1 ulp, 3-5 instructions
+// instead of the ~10-15 of the IEEE division sequence; Q_uu is a well-scaled positive number here.
+ILQR_DEV float fast_rcp(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+ILQR_DEV double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+
+// lane (i, j) <- lane (j, i) of the same 16-lane row: the 4x4 transpose is neither quad-local nor a
+// row rotation, so it goes through the LDS crossbar (ds_bpermute: one instruction, no LDS memory).
+ILQR_DEV float lane_transpose(float v, int src_byte) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_byte, __float_as_int(v)));
+}
+ILQR_DEV double lane_transpose(double v, int src_byte) {
+    const int lo = __builtin_amdgcn_ds_bpermute(src_byte, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src_byte, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// the two row contractions that share coefficients and rotation pattern (Q_ux from pu, Q_x from V_x).
+// (A packed v_pk_fma_f32 form of this pair was tried: hipcc assembled the register pairs through scratch
+// and the sweep ran 2.7x slower, so the two streams stay scalar.)
+template <typename T>
+ILQR_DEV void contract_row2(const T* skj, T w0, T w1, T c0, T c1, T& o0, T& o1) {
+    o0 = c0 + contract_row(skj, w0);
+    o1 = c1 + contract_row(skj, w1);
+}
+
+// per-lane constants of the sweep
+template <typename T> struct LaneConst {
+    T m0, m1;      // 1 where j == 0 / j == 1, else 0: fold l_u / l_uu (tile slots e_0, e_1) into the quad sums
+    int tr_byte;   // 4 * (lane of the transposed element)
+};
+
 // One Riccati step (iLQR_class.py:100-114) on the lane-distributed state:
 //   V  = V_xx[i][j] at lane (i, j);  vx = V_x[j] ("column form": replicated down the rows).
 // Returns K[j] (column form) and k (replicated); pd = Q_uu (+mu) > 0.
 template <typename T, bool REG>
-ILQR_DEV void tile16_step(const Tile16<T>& c, T mu, T& V, T& vx, T& Kj, T& kff, bool& pd) {
+ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V, T& vx, T& Kj, T& kff, bool& pd) {
     // P = f_x' V_xx :  P[i][j] = sum_d A[(i+d)%4][i] * V[(i+d)%4][j]
     T P = c.ski[0] * V;
     P += c.ski[1] * dpp<kDown1>(V);
@@ -115,25 +155,21 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, T mu, T& V, T& vx, T& Kj, T& kff, 
     T pu = c.bi * V;
     pu += dpp<kDown2>(pu);
     pu += dpp<kDown1>(pu);
-    // Q_xx = l_xx + P f_x ; Q_ux = l_ux + pu f_x ; Q_x = l_x + f_x' V_x
-    const T Qxx = c.lxx + contract_row(c.skj, P);
-    const T Qux = c.vj[2] + contract_row(c.skj, pu);
-    const T Qx = c.vj[1] + contract_row(c.skj, vx);
-    // Q_uu = l_uu + pu f_u ; Q_u = l_u + f_u' V_x
-    const T lu = dpp<dpp_quad(0, 0, 0, 0)>(c.vj[3]);
-    const T luu = dpp<dpp_quad(1, 1, 1, 1)>(c.vj[3]);
-    const T Quu = luu + quad_sum(pu * c.vj[0]);
-    const T Qu = lu + quad_sum(c.vj[0] * vx);
+    // Q_ux = l_ux + pu f_x ; Q_x = l_x + f_x' V_x  (same coefficients, same rotations: one packed stream)
+    T Qux, Qx;
+    contract_row2(c.skj, pu, vx, c.vj[2], c.vj[1], Qux, Qx);
+    // Q_uu = l_uu + pu f_u ; Q_u = l_u + f_u' V_x   (l_uu, l_u enter the quad sums on lanes j = 1, j = 0)
+    const T Quu = quad_sum(lc.m1 * c.vj[3] + pu * c.vj[0]);
+    const T Qu = quad_sum(lc.m0 * c.vj[3] + c.vj[0] * vx);
     const T Qr = REG ? Quu + mu : Quu;
     pd = Qr > T(0);
-    const T inv = T(1) / Qr;
+    const T inv = fast_rcp(Qr);
     Kj = -(Qux * inv);   // K = -Q_uu^-1 Q_ux   (:109)
     kff = -(Qu * inv);   // k = -Q_uu^-1 Q_u    (:110)
-    // Q_ux in "row form" (lane (i, j) <- Q_ux[i]) = the diagonal lane of each quad broadcast over it
-    T Quxi = dpp_row<dpp_quad(0, 0, 0, 0), 0x1>(Qux, Qux);
-    Quxi = dpp_row<dpp_quad(1, 1, 1, 1), 0x2>(Quxi, Qux);
-    Quxi = dpp_row<dpp_quad(2, 2, 2, 2), 0x4>(Quxi, Qux);
-    Quxi = dpp_row<dpp_quad(3, 3, 3, 3), 0x8>(Quxi, Qux);
+    // Q_ux in "row form": lane (i, j) <- Q_ux[i], held by lane (j, i)
+    const T Quxi = lane_transpose(Qux, lc.tr_byte);
+    // Q_xx = l_xx + P f_x
+    const T Qxx = c.lxx + contract_row(c.skj, P);
     if constexpr (!REG) {
         // short form (:113-114): V_x = Q_x + K'Q_u ; V_xx = Q_xx + Q_ux' K
         V = Qxx + Quxi * Kj;
@@ -146,18 +182,27 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, T mu, T& V, T& vx, T& Kj, T& kff, 
     }
 }
 
+// Workgroup = 4 waves = 16 trajectories, launched with > 80 KiB of (unused) dynamic LDS so that a CU
+// never hosts two workgroups: the 256 workgroups of a 4096-trajectory batch then sit one per CU and
+// their four waves one per SIMD.  (With 64-thread workgroups the dispatcher doubled waves up on ~8 % of
+// the SIMDs and left as many empty; an issue-bound wave that shares its SIMD runs ~1.35x longer and
+// the slowest wave is the kernel's duration.)
+constexpr int kTile16PinLds = 84 * 1024;
+
 template <typename T, bool REG>
-__global__ void __launch_bounds__(64) backward_tile16_kernel(KArgs<T> a) {
+__global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     constexpr int D = sizeof(T) == 4 ? 8 : 5;  // tiles in flight per lane (vmcnt holds 63 operations)
     constexpr int R = gain_record(4, 1);       // 8
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
-    const int gidx = blockIdx.x * 4 + (lane >> 4);
+    const int gidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     const bool valid = gidx < a.B;
     const int b = valid ? gidx : a.B - 1;  // out-of-range groups shadow the last trajectory, never store
     const int st = a.status[b];
     const bool act = valid && traj_active(st);
     if (__ballot(act) == 0ull) return;
+    ClockProbe cp;
+    cp.start();
     const size_t B = a.B;
     const int N = a.N;
     T V = a.term[(size_t)(4 + l16) * B + b];
@@ -168,11 +213,15 @@ __global__ void __launch_bounds__(64) backward_tile16_kernel(KArgs<T> a) {
     const bool storer = act && (i == 0 || l16 == 4);
     const size_t rstride = B * R;
     bool all_pd = true;
+    LaneConst<T> lc;
+    lc.m0 = T(j == 0);
+    lc.m1 = T(j == 1);
+    lc.tr_byte = 4 * ((lane & 48) | (j << 2) | i);
 
     auto do_step = [&](const Tile16<T>& c, int t) {
         T Kj, kff;
         bool pd;
-        tile16_step<T, REG>(c, a.mu, V, vx, Kj, kff, pd);
+        tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
         all_pd = all_pd && pd;
         if (storer) rec[(size_t)t * rstride] = (i == 0) ? Kj : kff;
     };
@@ -201,6 +250,142 @@ __global__ void __launch_bounds__(64) backward_tile16_kernel(KArgs<T> a) {
             }
         }
     }
+    cp.stop(a.probe, 0);
+    if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS-ring variant.  The register ring above leaves the s_waitcnt placement to hipcc, which drains
+// the whole ring at every loop edge (one exposed HBM latency per D steps).  Here the wave's four
+// tiles of one step -- 4 x 192 B (f32) contiguous in HBM because the four trajectories of a wave are
+// neighbours in b -- are copied HBM -> LDS by ONE LDS-DMA instruction (global_load_lds_dwordx4,
+// 48 lanes x 16 B; two for f64), RING steps ahead, with no VGPR destination.  The DMA and its wait
+// are inline asm, so the kernel counts vmcnt itself: each step issues exactly one store and NDMA
+// DMAs, hence "tile t has landed" == at most (RING-1)*(NDMA+1) younger operations outstanding
+// (loads, stores and LDS-DMA retire in issue order).  Tiles are then read LDS -> VGPR with
+// ds_read_b128/b32 (compiler-counted lgkmcnt), one step ahead of their use.
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct LdsRing;
+template <> struct LdsRing<float> { static constexpr int RING = 16, NDMA = 1; };
+template <> struct LdsRing<double> { static constexpr int RING = 12, NDMA = 2; };
+
+// one LDS-DMA piece: every active lane copies 16 B from its own global address to
+// LDS[m0_base + lane*16].  M0 is compiler-reserved: written and restored inside the statement.
+ILQR_DEV void lds_dma16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+template <int N> ILQR_DEV void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <typename T> ILQR_DEV void tile16_load_lds(Tile16<T>& tl, const T* tp, int i, int j, int l16) {
+    // tp: this trajectory's tile inside the LDS slot (generic pointer to __shared__)
+    using V4 = typename Vec4<T>::type;
+    const V4 a = *reinterpret_cast<const V4*>(tp + 4 * i);
+    const V4 c = *reinterpret_cast<const V4*>(tp + 4 * j);
+    const V4 v = *reinterpret_cast<const V4*>(tp + 32 + 4 * j);
+    tl.ski[0] = a.x; tl.ski[1] = a.y; tl.ski[2] = a.z; tl.ski[3] = a.w;
+    tl.skj[0] = c.x; tl.skj[1] = c.y; tl.skj[2] = c.z; tl.skj[3] = c.w;
+    tl.vj[0] = v.x; tl.vj[1] = v.y; tl.vj[2] = v.z; tl.vj[3] = v.w;
+    tl.lxx = tp[16 + l16];
+    tl.bi = tp[32 + 4 * i];
+}
+
+template <typename T, bool REG>
+__global__ void __launch_bounds__(64) backward_tile16_lds_kernel(KArgs<T> a) {
+    constexpr int RING = LdsRing<T>::RING, NDMA = LdsRing<T>::NDMA;
+    constexpr int R = gain_record(4, 1);
+    constexpr int SLOT = 4 * kTile16;                    // scalars per ring slot (4 trajectories)
+    constexpr int SLOT_BYTES = SLOT * (int)sizeof(T);    // 768 / 1536
+    constexpr int PIECES = SLOT_BYTES / 16;              // 16-B pieces per slot: 48 / 96
+    __shared__ __attribute__((aligned(16))) T ring[RING * SLOT];
+    const int lane = threadIdx.x;
+    const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3, grp = lane >> 4;
+    const int gidx = blockIdx.x * 4 + grp;
+    const bool valid = gidx < a.B;
+    const int b = valid ? gidx : a.B - 1;
+    const int st = a.status[b];
+    const bool act = valid && traj_active(st);
+    if (__ballot(act) == 0ull) return;
+    ClockProbe cp;
+    cp.start();
+    const size_t B = a.B;
+    const int N = a.N;
+    T V = a.term[(size_t)(4 + l16) * B + b];
+    T vx = a.term[(size_t)j * B + b];
+    T* __restrict__ rec = a.gains + (size_t)b * R + (i == 0 ? j : 4);
+    const bool storer = act && (i == 0 || l16 == 4);
+    const size_t rstride = B * R;
+    bool all_pd = true;
+
+    LaneConst<T> lc;
+    lc.m0 = T(j == 0);
+    lc.m1 = T(j == 1);
+    lc.tr_byte = 4 * ((lane & 48) | (j << 2) | i);
+
+    // DMA source of this lane: piece q of the slot = 16 B number (q % per_tile) of trajectory (q / per_tile)
+    constexpr int PER_TILE = PIECES / 4;  // 12 / 24
+    const char* src[NDMA];
+    bool dma_lane[NDMA];
+#pragma unroll
+    for (int d = 0; d < NDMA; ++d) {
+        const int q = lane + 64 * d;
+        dma_lane[d] = q < PIECES;
+        const int qq = dma_lane[d] ? q : 0;
+        int bb = blockIdx.x * 4 + qq / PER_TILE;
+        bb = bb < a.B ? bb : a.B - 1;  // a tail wave re-reads the last trajectory, never out of bounds
+        src[d] = reinterpret_cast<const char*>(a.lin + (size_t)bb * kTile16) + (qq % PER_TILE) * 16;
+    }
+    const size_t tbytes = B * kTile16 * sizeof(T);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) T*)ring;
+
+    auto issue = [&](int t_tile, int slot) {
+        const int tt = t_tile > 0 ? t_tile : 0;  // past the end of the sweep: harmless re-read of tile 0
+#pragma unroll
+        for (int d = 0; d < NDMA; ++d)
+            if (dma_lane[d])
+                lds_dma16(src[d] + (size_t)tt * tbytes,
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + slot * SLOT_BYTES + d * 1024)));
+    };
+
+    // prologue: RING tiles in flight
+    for (int u = 0; u < RING; ++u) issue(N - 1 - u, u);
+
+    const T* mine = ring + grp * kTile16;
+    Tile16<T> cur, nxt;
+    wait_vmcnt<(RING - 1) * NDMA>();  // only DMAs so far: tile N-1 has landed
+    tile16_load_lds(cur, mine, i, j, l16);
+    int slot = 0;
+    // One step.  Before tile t-1 (next slot) is read into registers one step ahead of its use, its DMA
+    // must have retired.  Operations younger than that DMA: in steady state (RING-2) whole steps of
+    // {1 store, NDMA DMAs}; during the first RING-2 steps fewer stores have been issued yet, so the
+    // count there is bounded below by (RING-2)*NDMA -- the tight bound is used for those steps.
+    auto body = [&](int t, auto wtag) {
+        const int nslot = (slot + 1 == RING) ? 0 : slot + 1;
+        wait_vmcnt<decltype(wtag)::value>();
+        tile16_load_lds(nxt, mine + nslot * SLOT, i, j, l16);
+        T Kj, kff;
+        bool pd;
+        tile16_step<T, REG>(cur, lc, a.mu, V, vx, Kj, kff, pd);
+        all_pd = all_pd && pd;
+        if (storer) rec[(size_t)t * rstride] = (i == 0) ? Kj : kff;
+        // slot `slot` has been consumed (its values are in `cur`, already used): refill it RING steps ahead
+        issue(t - RING, slot);
+        cur = nxt;
+        slot = nslot;
+    };
+    int t = N - 1;
+    for (int s = 0; s < RING - 2 && t >= 0; ++s, --t) body(t, std::integral_constant<int, (RING - 2) * NDMA>());
+    for (; t >= 0; --t) body(t, std::integral_constant<int, (RING - 2) * (NDMA + 1)>());
+    wait_vmcnt<0>();  // drain the DMAs that ran past the end before the LDS allocation is released
+    cp.stop(a.probe, 0);
     if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
 }
 

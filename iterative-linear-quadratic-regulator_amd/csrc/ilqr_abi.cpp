@@ -177,6 +177,11 @@ int ilqr_mpc_run(ilqr_handle h, int n_steps, void* u_out, void* x_out, void* cos
     ILQR_FWD(h, mpc_run(n_steps, u_out, x_out, cost_out));
 }
 int ilqr_status_reduce(ilqr_handle h, void* dev_out4) { ILQR_FWD(h, status_reduce(dev_out4)); }
+/* diagnostic (not in the public header): raw clock-probe buffer, valid when ILQR_CLOCK_PROBE was set */
+int ilqr_debug_probe_dump(ilqr_handle h, long long* dst, size_t n) {
+    if (!h || !h->impl) return ILQR_ERR_INVALID_ARG;
+    return h->impl->probe_dump(dst, n);
+}
 int ilqr_timing_enable(ilqr_handle h, int on) { ILQR_FWD(h, timing_enable(on)); }
 int ilqr_timing_reset(ilqr_handle h) { ILQR_FWD(h, timing_reset()); }
 int ilqr_timing_get(ilqr_handle h, double ms[ILQR_N_PHASES], int64_t launches[ILQR_N_PHASES]) {

@@ -35,11 +35,34 @@ template <typename T> struct KArgs {
     T* costs; T* cost; T* cost_prev; T* alpha_taken;
     int* status; int* iters; int* accepted; int* counters;
     const T* params;
+    long long* probe;  // diagnostic: {shader cycles, 100 MHz ticks} of block 0 per kernel, or nullptr
 };
 
 constexpr int gain_record(int nx, int nu) { return ((nu * nx + nu) + 3) / 4 * 4; }
 
 ILQR_DEV bool traj_active(int status) { return (status & 0xff) == ILQR_TRAJ_ACTIVE; }
+
+// Clock probe (diagnostic only; the values go to a buffer nothing else reads): one pair of stamps around
+// a whole kernel body for lane 0 of workgroup 0 gives cycles per step and the clock the chip holds.
+struct ClockProbe {
+    long long c0, r0;
+    ILQR_DEV void start() { c0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }
+    // slot 0: backward (from probe[8]), slot 1: forward (from probe[8 + 4*65536]); per workgroup 4 longs:
+    // {start tick, end tick, cycles, HW_ID}.  probe[2*slot], [2*slot+1] keep workgroup 0's {cycles, ticks}.
+    ILQR_DEV void stop(long long* probe, int slot) const {
+        if (probe && threadIdx.x == 0) {
+            const long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+            const size_t wg = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            if (wg == 0) { probe[2 * slot] = c1 - c0; probe[2 * slot + 1] = r1 - r0; }
+            if (wg < 65536) {
+                long long* q = probe + 8 + ((size_t)slot * 65536 + wg) * 4;
+                q[0] = r0; q[1] = r1; q[2] = c1 - c0;
+                q[3] = (long long)__builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11)) |
+                       ((long long)__builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11)) << 32);
+            }
+        }
+    }
+};
 
 }  // namespace ilqr
 #include "backward_tile16.hpp"
@@ -419,6 +442,8 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     T x[NX], u[NU];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = a.x0[(size_t)i * B + b];
+    ClockProbe cp;
+    cp.start();
     T cost = T(0);
     const T* Xo = a.X + ((size_t)slot * (N + 1) * NX) * B + b;
     const T* Uo = a.U + ((size_t)slot * N * NU) * B + b;
@@ -471,6 +496,7 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
     cost += Cost<T, Dyn>::terminal(p, x);
     a.costs[(size_t)ai * B + b] = cost;
+    cp.stop(a.probe, 1);
 }
 
 // ---------------------------------------------------------------------------

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -42,6 +43,7 @@ struct SolverBase {
     virtual int mpc_reset(const void* x0, const void* U) = 0;
     virtual int mpc_run(int n_steps, void* u_out, void* x_out, void* cost_out) = 0;
     virtual int status_reduce(void* dev_out4) = 0;
+    virtual int probe_dump(long long* dst, size_t n) = 0;
     virtual int timing_enable(int on) = 0;
     virtual int timing_reset() = 0;
     virtual int timing_get(double* ms, int64_t* launches) = 0;
@@ -106,10 +108,26 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
     if constexpr (TILE) {
         // one wave = 4 trajectories x 16 lanes; 1024 single-wave workgroups at B = 4096 = one per SIMD
         o.backward = [](const KArgs<T>& a, hipStream_t s) {
-            if (a.mu != T(0))
-                hipLaunchKernelGGL((backward_tile16_kernel<T, true>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
-            else
-                hipLaunchKernelGGL((backward_tile16_kernel<T, false>), dim3((a.B + 3) / 4), dim3(64), 0, s, a);
+            static const bool lds_ring = getenv("ILQR_BACKWARD_LDS_RING") != nullptr;  // A/B switch for profiling
+            if (lds_ring) {
+                const dim3 grid((a.B + 3) / 4), block(64);
+                if (a.mu != T(0)) hipLaunchKernelGGL((backward_tile16_lds_kernel<T, true>), grid, block, 0, s, a);
+                else hipLaunchKernelGGL((backward_tile16_lds_kernel<T, false>), grid, block, 0, s, a);
+                return;
+            }
+            // 16 trajectories per 256-thread workgroup, one workgroup per CU (see kTile16PinLds)
+            static const bool pinned = [] {
+                bool ok = hipFuncSetAttribute((const void*)backward_tile16_kernel<T, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTile16PinLds) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)backward_tile16_kernel<T, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTile16PinLds) == hipSuccess;
+                (void)hipGetLastError();
+                return ok && getenv("ILQR_BACKWARD_NO_PIN") == nullptr;
+            }();
+            const dim3 grid((a.B + 15) / 16), block(256);
+            const size_t lds = pinned ? kTile16PinLds : 0;
+            if (a.mu != T(0)) hipLaunchKernelGGL((backward_tile16_kernel<T, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((backward_tile16_kernel<T, false>), grid, block, lds, s, a);
         };
     } else {
         o.backward = [](const KArgs<T>& a, hipStream_t s) {
@@ -239,6 +257,9 @@ template <typename T> class SolverT : public SolverBase {
     T* plant_x = nullptr;
     T *mpc_u_log = nullptr, *mpc_x_log = nullptr, *mpc_cost_log = nullptr;
     int mpc_log_steps = 0;
+    long long* probe = nullptr;  // device, 8 x int64 (see ClockProbe)
+    bool probe_on = false;
+    size_t probe_elems = 8;
     int* h_counter = nullptr;  // pinned
     std::vector<double> trial_alphas;
     PhaseTimer timer;
@@ -252,6 +273,7 @@ template <typename T> class SolverT : public SolverBase {
         hipFree(params);
         hipFree(staging);
         hipFree(plant_x);
+        hipFree(probe);
         hipFree(mpc_u_log);
         hipFree(mpc_x_log);
         hipFree(mpc_cost_log);
@@ -326,6 +348,10 @@ template <typename T> class SolverT : public SolverBase {
         ILQR_HIPCHK(hipMalloc((void**)&staging, staging_elems * sizeof(T)));
         ILQR_HIPCHK(hipMalloc((void**)&plant_x, (size_t)NX * B * sizeof(T)));
         ILQR_HIPCHK(hipMemsetAsync(plant_x, 0, (size_t)NX * B * sizeof(T), stream));
+        probe_on = getenv("ILQR_CLOCK_PROBE") != nullptr;
+        probe_elems = probe_on ? (8 + 2 * 65536 * 4) : 8;
+        ILQR_HIPCHK(hipMalloc((void**)&probe, probe_elems * sizeof(long long)));
+        ILQR_HIPCHK(hipMemsetAsync(probe, 0, probe_elems * sizeof(long long), stream));
         ILQR_HIPCHK(hipHostMalloc((void**)&h_counter, kCounterRing * sizeof(int)));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
         return ILQR_OK;
@@ -338,6 +364,7 @@ template <typename T> class SolverT : public SolverBase {
         a.X = s.X; a.U = s.U; a.cur_slot = s.cur_slot; a.gains = s.gains; a.lin = s.lin; a.term = s.term;
         a.x0 = s.x0; a.costs = s.costs; a.cost = s.cost; a.cost_prev = s.cost_prev; a.alpha_taken = s.alpha_taken;
         a.status = s.status; a.iters = s.iters; a.accepted = s.accepted; a.counters = s.counters; a.params = params;
+        a.probe = probe_on ? probe : nullptr;
         return a;
     }
 
@@ -456,6 +483,7 @@ template <typename T> class SolverT : public SolverBase {
             case ILQR_X0: case ILQR_PLANT_X: return b * NX * sizeof(T);
             case ILQR_COST: case ILQR_ALPHA: return b * sizeof(T);
             case ILQR_STATUS: case ILQR_ITERS: return b * sizeof(int32_t);
+            case ILQR_PROBE: return 8 * sizeof(long long);
             case ILQR_TRIAL_COSTS: return b * A * sizeof(T);
             case ILQR_LIN: return b * N * E * sizeof(T);
             default: return 0;
@@ -494,6 +522,7 @@ template <typename T> class SolverT : public SolverBase {
             case ILQR_ALPHA: ILQR_HIPCHK(hipMemcpyAsync(dst, st.alpha_taken, bytes, hipMemcpyDeviceToHost, stream)); return sync();
             case ILQR_STATUS: ILQR_HIPCHK(hipMemcpyAsync(dst, st.status, bytes, hipMemcpyDeviceToHost, stream)); return sync();
             case ILQR_ITERS: ILQR_HIPCHK(hipMemcpyAsync(dst, st.iters, bytes, hipMemcpyDeviceToHost, stream)); return sync();
+            case ILQR_PROBE: ILQR_HIPCHK(hipMemcpyAsync(dst, probe, bytes, hipMemcpyDeviceToHost, stream)); return sync();
             default: err = "get: unknown field"; return ILQR_ERR_INVALID_ARG;
         }
     }
@@ -769,6 +798,12 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = fetch(u_out, mpc_u_log, NU))) return rc;
         if ((rc = fetch(x_out, mpc_x_log, NX))) return rc;
         if ((rc = fetch(cost_out, mpc_cost_log, 1))) return rc;
+        return sync();
+    }
+
+    int probe_dump(long long* dst, size_t n) override {
+        if (!dst || n > probe_elems) { err = "probe_dump: bad size"; return ILQR_ERR_INVALID_ARG; }
+        ILQR_HIPCHK(hipMemcpyAsync(dst, probe, n * sizeof(long long), hipMemcpyDeviceToHost, stream));
         return sync();
     }
 

@@ -1,0 +1,96 @@
+"""Multi-GPU sharding of the batched solve: one process per GPU, each owning a
+contiguous shard of independent trajectories; no trajectory data ever crosses GPUs.  The only
+exchange is a scalar all-reduce of {min cost, max |dcost|, #active, #converged} so that every rank
+knows the best cost and whether the whole job has converged -- RCCL over xGMI on the GPUs
+(``torch.distributed`` backend "nccl"), gloo in the CPU tests.
+
+The reference has no counterpart (it is a single process); the semantics follow its loop
+(iLQR_class.py:267, 304-311) applied to the union of all shards.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+def shard_range(total: int, world: int, rank: int):
+    """Contiguous [lo, hi) of `total` trajectories owned by `rank`; sizes differ by at most one."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world of {world}")
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+@dataclass
+class GlobalStatus:
+    min_cost: float
+    max_dcost: float
+    n_active: int
+    n_converged: int
+
+
+def allreduce_status(stats4, group=None):
+    """In-place all-reduce of a 4-vector {min cost, max |dcost|, #active, #converged} (float64 tensor,
+    on the GPU for nccl/RCCL or on the CPU for gloo): MIN, MAX, SUM, SUM -- as two collectives
+    (-min and max share one MAX)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return stats4
+    mm = torch.stack([-stats4[0], stats4[1]])
+    dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
+    cnt = stats4[2:4].clone()
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    stats4[0] = -mm[0]
+    stats4[1] = mm[1]
+    stats4[2:4] = cnt
+    return stats4
+
+
+def to_status(stats4) -> GlobalStatus:
+    v = [float(x) for x in stats4.tolist()]
+    return GlobalStatus(min_cost=v[0], max_dcost=v[1], n_active=int(round(v[2])), n_converged=int(round(v[3])))
+
+
+def local_stats(cost, cost_prev, status):
+    """Host-side twin of the device kernel status_reduce_kernel (csrc/kernels.hpp), used by the CPU
+    tests and by callers that already hold host copies: returns a float64 CPU tensor of 4."""
+    import numpy as np
+    import torch
+    cost = np.asarray(cost, dtype=np.float64)
+    cost_prev = np.asarray(cost_prev, dtype=np.float64)
+    st = np.asarray(status) & 0xff
+    return torch.tensor([cost.min(), np.abs(cost - cost_prev).max(), float((st == 0).sum()), float((st == 1).sum())],
+                        dtype=torch.float64)
+
+
+class ShardedBatch:
+    """Splits a global batch (x0 (B, n), U_init (B, m, N)) over the ranks of the default process group
+    and solves the local shard with ``iLQR``; ``global_status()`` is the RCCL all-reduce."""
+
+    def __init__(self, system_factory, x0, U_init, device=None, **ilqr_kw):
+        import torch
+        import torch.distributed as dist
+        from .iLQR_class import iLQR
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.lo, self.hi = shard_range(len(x0), self.world, self.rank)
+        if device is None:
+            device = torch.cuda.current_device()
+        self.solver = iLQR(system_factory(), None, x0[self.lo:self.hi], U_init[self.lo:self.hi],
+                           device=device, verbose=False, **ilqr_kw)
+        self._stats = torch.zeros(4, dtype=torch.float64, device=f"cuda:{device}")
+
+    def solve(self):
+        X, U, cost = self.solver.optimize_trajectory()
+        return X, U, cost
+
+    def global_status(self) -> GlobalStatus:
+        import torch
+        h = self.solver.handle
+        h.status_reduce(self._stats.data_ptr())
+        h.sync()
+        torch.cuda.synchronize()
+        allreduce_status(self._stats)
+        return to_status(self._stats.cpu())

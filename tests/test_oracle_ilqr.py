@@ -1,0 +1,157 @@
+"""Pins the oracle's solver layer (oracle/ilqr.py) -- CPU only.
+
+ * linear-quadratic known answer (matlab/CLASSES/Linear_iLQR_CLASS.m:56-139): the iLQR gains equal
+   the finite-horizon discrete Riccati recursion, and one alpha = 1 iteration reaches the optimum;
+ * the independently written C restatement (oracle/c/ilqr_oracle.c) agrees with the NumPy one;
+ * the committed golden fixtures (tests/golden/*.npz) still reproduce;
+ * behavioural quirks of the reference loop.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from ilqr_amd import problems
+from oracle import backward_pass, forward_pass, iLQROracle, mpc_closed_loop, horizon_steps
+from oracle.build import oracle_from_spec
+from oracle.c_oracle import COracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _lq(n=4, m=2, N=30, seed=0):
+    p = problems.linear_quadratic(n=n, m=m, N=N, seed=seed)
+    return p, oracle_from_spec(p["dynamics"], p["cost"])
+
+
+def test_lq_gains_equal_discrete_riccati_recursion():
+    p, orc = _lq()
+    N, dt = p["N"], p["dynamics"]["dt"]
+    A, B = p["dynamics"]["A"], p["dynamics"]["B"]
+    Q, R, Qf = p["cost"]["Q"] * dt, p["cost"]["R"] * dt, p["cost"]["Q_f"]
+    rng = np.random.default_rng(0)
+    X, U = rng.standard_normal((4, N + 1)), rng.standard_normal((2, N))
+    _, K = backward_pass(orc, X, U)
+    P = Qf.copy()
+    for t in range(N - 1, -1, -1):  # textbook finite-horizon LQR
+        Kt = -np.linalg.solve(R + B.T @ P @ B, B.T @ P @ A)
+        np.testing.assert_allclose(K[t], Kt, rtol=1e-9, atol=1e-12)
+        P = Q + A.T @ P @ A + A.T @ P @ B @ Kt
+
+
+def test_lq_converges_in_one_full_step():
+    """For linear dynamics + quadratic cost the first alpha = 1 step lands on the optimum: the second
+    iteration cannot improve the cost by more than rounding."""
+    p, orc = _lq()
+    x0, U0 = problems.lq_batch(1, 4, 2, p["N"])
+    o = iLQROracle(orc, N=p["N"], x_0=x0[0], U_init=U0[0], tol=1e-9, maxiter=5)
+    o.optimize_trajectory()
+    assert o.history[0][1] == 1.0
+    assert o.status == "converged" and o.iterations == 2
+    assert abs(o.history[1][2] - o.history[0][2]) <= 1e-9 * abs(o.history[0][2])
+
+
+@pytest.mark.parametrize("name", ["pendulum", "ua", "dp"])
+@pytest.mark.parametrize("integ", ["euler", "midpoint", "rk4", "backward_euler"])
+def test_c_oracle_agrees_with_numpy_oracle(name, integ):
+    p = {"pendulum": problems.pendulum_open_loop(N=60), "ua": problems.ua_double_pendulum(N=40),
+         "dp": problems.double_pendulum(N=30)}[name]
+    dyn = dict(p["dynamics"], integrator=integ)
+    co, no = COracle(dyn, p["cost"]), oracle_from_spec(dyn, p["cost"])
+    rng = np.random.default_rng(0)
+    n, m, N = co.n, co.m, p["N"]
+    X, U = rng.standard_normal((n, N + 1)) * 0.5, rng.standard_normal((m, N)) * 0.5
+    a, b = co.backward_pass(X, U)
+    c, d = backward_pass(no, X, U)
+    np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(b, d, rtol=1e-9, atol=1e-12)
+    x0 = rng.standard_normal(n) * 0.3
+    f, g = co.forward_pass(x0, 0.5, X, U, a * 0.1, b * 0.1), forward_pass(no, x0, 0.5, X, U, a * 0.1, b * 0.1)
+    for u, v in zip(f, g):
+        np.testing.assert_allclose(u, v, rtol=1e-10, atol=1e-12)
+
+
+def test_c_oracle_full_solve_agrees():
+    p = problems.ua_double_pendulum(N=50)
+    x0, U0 = problems.ua_batch(2, seed=0, restarts=True, N=50)
+    co, no = COracle(p["dynamics"], p["cost"]), oracle_from_spec(p["dynamics"], p["cost"])
+    for b in range(2):
+        r = co.solve(x0[b], U0[b], maxiter=10)
+        o = iLQROracle(no, N=50, x_0=x0[b], U_init=U0[b], maxiter=10)
+        _, _, c = o.optimize_trajectory()
+        assert (r["iterations"], r["status"]) == (o.iterations, o.status)
+        np.testing.assert_allclose(r["cost"], c, rtol=1e-9)
+        np.testing.assert_allclose(r["K"], o.K, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "c*_*.npz")) + glob.glob(os.path.join(GOLD, "dp_*.npz"))))
+def test_golden_fixtures_reproduce(path):
+    g = np.load(path)
+    name = os.path.basename(path)
+    base = {"c1": problems.pendulum_open_loop(), "c2": problems.ua_double_pendulum(), "dp": problems.double_pendulum()}[
+        name.split("_")[0]]
+    orc = oracle_from_spec(dict(base["dynamics"], integrator=str(g["integrator"])), base["cost"])
+    N = int(g["N"])
+    b = 0
+    uff, K = backward_pass(orc, g["rollout_X"][b], g["rollout_U"][b])
+    np.testing.assert_allclose(K, g["first_K"][b], rtol=1e-10, atol=1e-13)
+    np.testing.assert_allclose(uff, g["first_Uff"][b], rtol=1e-10, atol=1e-13)
+    o = iLQROracle(orc, N=N, x_0=g["x0"][b], U_init=g["U_init"][b], tol=float(g["tol"]), maxiter=int(g["maxiter"]))
+    _, _, c = o.optimize_trajectory()
+    np.testing.assert_allclose(c, g["cost"][b], rtol=1e-10)
+    assert o.status == str(g["status"][b]) and o.iterations == int(g["iterations"][b])
+
+
+def test_acceptance_is_first_alpha_not_best_alpha():
+    """backtracking accepts the FIRST alpha in {1, 1/2, ...} with cost_new <= cost."""
+    p = problems.ua_double_pendulum(N=60)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    x0, U0 = problems.ua_batch(1, seed=4, restarts=True, N=60)
+    o = iLQROracle(orc, N=60, x_0=x0[0], U_init=U0[0], maxiter=1)
+    o.optimize_trajectory()
+    it, alpha, cost = o.history[0]
+    o2 = iLQROracle(orc, N=60, x_0=x0[0], U_init=U0[0], maxiter=0)
+    o2.optimize_trajectory()
+    c0 = o2.initial_cost
+    uff, K = backward_pass(orc, o2.X, o2.U)
+    a = 1.0
+    while a > alpha:  # every larger alpha must have been rejected
+        assert forward_pass(orc, x0[0], a, o2.X, o2.U, uff, K)[2] > c0
+        a *= 0.5
+    assert forward_pass(orc, x0[0], alpha, o2.X, o2.U, uff, K)[2] <= c0
+
+
+def test_mpc_state_carry_between_solves():
+    """the initial rollout of every solve goes through the PREVIOUS solve's K and X."""
+    p = problems.pendulum_mpc(N=30)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    plant = oracle_from_spec(p["dynamics"], p["cost"], integrator="midpoint")
+    o = iLQROracle(orc, N=30, x_0=p["x0"], U_init=p["U_init"], maxiter=3)
+    X, U, c = mpc_closed_loop(o, plant, p["x0"], p["U_init"], 3)
+    fresh = iLQROracle(orc, N=30, x_0=X[:, 2], U_init=np.concatenate([o.U[:, 1:], o.U[:, -1:]], 1), maxiter=3)
+    fresh.optimize_trajectory()
+    assert np.isfinite(c).all() and X.shape == (2, 4)
+    g = np.load(os.path.join(GOLD, "mpc_pendulum.npz"))
+    o2 = iLQROracle(oracle_from_spec(problems.pendulum_mpc(N=40)["dynamics"], p["cost"]), N=40, x_0=p["x0"],
+                    U_init=np.zeros((1, 40)), maxiter=p["maxiter"])
+    X2, U2, c2 = mpc_closed_loop(o2, plant, p["x0"], np.zeros((1, 40)), int(g["n_sim"]))
+    np.testing.assert_allclose(c2, g["cost"], rtol=1e-10)
+    np.testing.assert_allclose(U2, g["U_sim"], rtol=1e-9, atol=1e-12)
+
+
+def test_horizon_and_shape_errors():
+    assert horizon_steps(4.0, 0.01) == 400 and horizon_steps(2.0, 0.01) == 200 and horizon_steps(1.0, 0.01) == 100
+    p = problems.pendulum_open_loop(N=100)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    with pytest.raises(ValueError, match="U_init must have shape"):   # iLQR_class.py:50-52
+        iLQROracle(orc, T=1.0, x_0=p["x0"], U_init=np.zeros((1, 99)))
+
+
+def test_fp32_switch_stays_fp32():
+    p = problems.ua_double_pendulum(N=20)
+    orc = oracle_from_spec(p["dynamics"], p["cost"], dtype=np.float32)
+    x0, U0 = problems.ua_batch(1, seed=0, restarts=True, N=20)
+    o = iLQROracle(orc, N=20, x_0=x0[0], U_init=U0[0], maxiter=2)
+    X, U, c = o.optimize_trajectory()
+    assert X.dtype == np.float32 and o.K.dtype == np.float32 and np.asarray(c).dtype == np.float32
