@@ -36,23 +36,50 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-def cpu_baseline(p, n_alpha, dtype, budget_s=12.0):
-    """The oracle's C restatement of the reference loop (sequential backtracking, one trajectory
-    per call) on the host cores: a bounded sample of the same workload, all cores via fork."""
+def pmc_traffic(dtype, batch, horizon):
+    """HBM bytes per backward launch from the committed rocprofv3 PMC passes (profiles/rNN/pmc_traffic_*.json;
+    FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).  Counters cannot be read from inside this
+    process, so the figure is the profiled one for the same (dtype, batch, horizon), else None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{dtype}.json"))):
+        try:
+            d = json.load(open(path))
+            if d.get("batch") == batch and d.get("horizon") == horizon:
+                best = (float(d["kernels"]["backward_tile16_kernel"]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT))
+        except Exception:
+            pass
+    return best
+
+
+def host_cores():
+    """Cores this process may actually use (the GPU box gives a 1-GPU job a share of the host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, os.cpu_count() or n, int(os.environ.get("ILQR_BENCH_CORES", "16"))))
+
+
+def cpu_baseline(p, dtype, budget_s=10.0):
+    """The oracle's C restatement of the reference loop (oracle/c/ilqr_oracle.c: per-timestep backward
+    and forward passes, SEQUENTIAL backtracking that stops at the first accepted alpha, one trajectory
+    per call) on the host cores: a bounded sample of the same workload, one forked worker per core."""
     import multiprocessing as mp
     from oracle.c_oracle import COracle, build
     from ilqr_amd import problems
     build()
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     iters = 10
     np_dt = np.float64 if dtype == "f64" else np.float32
-    # calibrate on one trajectory, then size the sample to the budget
-    x0, U0 = problems.ua_batch(max(cores * 4, 64), seed=0, restarts=False, N=p["N"])
+    x0, U0 = problems.ua_batch(256, seed=0, restarts=False, N=p["N"])
     co = COracle(p["dynamics"], p["cost"], dtype=np_dt)
+    co.solve(x0[0], U0[0], fixed_iters=iters)  # warm
     t0 = time.perf_counter()
-    co.solve(x0[0], U0[0], fixed_iters=iters)
-    t1 = time.perf_counter() - t0
-    per_core = max(1, min(len(x0) // cores, int(budget_s / max(t1, 1e-6))))
+    for i in range(8):
+        co.solve(x0[i], U0[i], fixed_iters=iters)
+    t1 = (time.perf_counter() - t0) / 8
+    per_core = max(8, int(budget_s / max(t1, 1e-6)))
     n_traj = per_core * cores
 
     def work(rank, q):
@@ -71,9 +98,9 @@ def cpu_baseline(p, n_alpha, dtype, budget_s=12.0):
         pr.join()
     wall = time.perf_counter() - t0
     return {"value": n_traj * iters / wall, "unit": "iLQR iterations/sec", "cores": cores, "kind": "port",
-            "single_core_value": iters / t1,
-            "sample": f"{n_traj} trajectories x {iters} iterations of the same problem (C restatement of the "
-                      f"reference loop, {dtype}, sequential backtracking), {cores} processes"}
+            "single_core_value": iters / t1, "host_cpu_count": os.cpu_count(),
+            "sample": f"{n_traj} trajectories x {iters} iterations of the same c3 problem ({dtype}); C restatement of the "
+                      f"reference loop with its sequential backtracking; {cores} worker processes, {wall:.1f} s"}
 
 
 def main():
@@ -88,14 +115,21 @@ def main():
     ap.add_argument("--no-phase-timing", action="store_true")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    import ilqr_amd
-    from ilqr_amd import _lib, problems
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    import ilqr_amd
+    from ilqr_amd import _lib, problems
+    p = problems.ua_double_pendulum(integrator="rk4", N=200)
+    # CPU baseline first: its worker processes are forked before this process touches the GPU
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(p, args.dtype)
+
+    import torch
+    import torch.distributed as dist
+    from ilqr_amd.dist import allreduce_status
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus}` "
                          f"(WORLD_SIZE is {world})")
@@ -107,7 +141,6 @@ def main():
         dist.init_process_group("nccl")  # RCCL
 
     np_dt = np.float64 if args.dtype == "f64" else np.float32
-    p = problems.ua_double_pendulum(integrator="rk4", N=200)
     B, N = args.batch, p["N"]
     x0, U0 = problems.ua_batch(B, seed=1000 + rank, restarts=False, N=N)
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
@@ -124,9 +157,7 @@ def main():
         if world > 1:
             # the path's only inter-GPU exchange: best cost / convergence
             h.status_reduce(stats.data_ptr())
-            neg = torch.stack([-stats[0], stats[1]])
-            dist.all_reduce(neg, op=dist.ReduceOp.MAX)
-            dist.all_reduce(stats[2:], op=dist.ReduceOp.SUM)
+            allreduce_status(stats)
 
     def fence():
         if world > 1:
@@ -174,18 +205,21 @@ def main():
             ms, n = phases["backward"]
             avg_s = ms / max(n, 1) * 1e-3
             achieved = ab["backward"] / avg_s / 1e9
-            out["roofline"] = {"bound": "hbm", "kernel": "backward Riccati sweep", "achieved": achieved,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": None, "algorithmic_bytes_per_launch": ab["backward"],
-                               "avg_launch_us": avg_s * 1e6, "launches": n}
+            tr = pmc_traffic(args.dtype, B, N)
+            out["roofline"] = {"bound": "hbm", "kernel": "backward Riccati sweep (backward_tile16_kernel)",
+                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                               "traffic_source": tr[1] if tr else None,
+                               "algorithmic_bytes_per_launch": ab["backward"], "avg_launch_us": avg_s * 1e6,
+                               "launches": n, "frac_of_measured_copy_peak_6.29TBs": achieved / 6290.0}
             out["phases_us_per_step"] = {k: 1e3 * v[0] / args.steps for k, v in phases.items()}
         if os.environ.get("ILQR_CLOCK_PROBE"):
             pr = h.get(_lib.PROBE)
             out["clock_probe"] = {"backward_cycles": int(pr[0]), "backward_GHz": float(pr[0]) / max(float(pr[1]), 1) * 0.1,
                                   "forward_cycles": int(pr[2]), "forward_GHz": float(pr[2]) / max(float(pr[3]), 1) * 0.1}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p, args.n_alpha, args.dtype)
-            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

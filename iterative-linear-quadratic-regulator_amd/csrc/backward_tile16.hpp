@@ -68,6 +68,54 @@ template <> struct Vec4<double> { using type = double4; };
 
 constexpr int kTile16 = 48;
 
+// ---- buffer addressing (SRSRC): address = base + voffset(lane, set once) + soffset(scalar, per step) +
+// immediate.  The sweep's per-step address arithmetic is then ONE scalar multiply instead of four 64-bit
+// vector adds per tile (cdna_hip_programming.md T8: it pays "as part of other addressing idioms").
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+// Uniformity must be PROVABLE to hipcc or every buffer op is wrapped in a ~10-instruction waterfall loop
+// (cdna_hip_programming.md T20): the descriptor inputs and every soffset go through readfirstlane.
+ILQR_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+ILQR_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    const unsigned lo = (unsigned)uniform((int)(unsigned)a), hi = (unsigned)uniform((int)(unsigned)(a >> 32));
+    void* ub = (void*)(((unsigned long long)hi << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(ub, 0, (unsigned)uniform((int)bytes), 0x00020000);
+}
+// 4 scalars of T at voff + IMM_SCALARS*sizeof(T)
+template <int IMM, typename T> struct BufLoad;
+template <int IMM> struct BufLoad<IMM, float> {
+    static ILQR_DEV void v4(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 4, soff, 0);
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+    }
+    static ILQR_DEV float v1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff + IMM * 4, soff, 0));
+    }
+};
+template <int IMM> struct BufLoad<IMM, double> {
+    static ILQR_DEV void v4(__amdgpu_buffer_rsrc_t r, int voff, int soff, double* o) {
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 8, soff, 0);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 8 + 16, soff, 0);
+        o[0] = __hiloint2double((int)a.y, (int)a.x); o[1] = __hiloint2double((int)a.w, (int)a.z);
+        o[2] = __hiloint2double((int)b.y, (int)b.x); o[3] = __hiloint2double((int)b.w, (int)b.z);
+    }
+    static ILQR_DEV double v1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM * 8, soff, 0);
+        return __hiloint2double((int)a.y, (int)a.x);
+    }
+};
+ILQR_DEV void buf_store1(__amdgpu_buffer_rsrc_t r, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, soff, 0);
+}
+ILQR_DEV void buf_store1(__amdgpu_buffer_rsrc_t r, int voff, int soff, double v) {
+    u32x2 w = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v)};
+    __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
+}
+
+// per-lane byte offsets into this trajectory's tile, fixed for the whole sweep
+struct TileOffsets { int vi, vj, vl; };
+
 template <typename T> struct Tile16 {
     T ski[4];  // SK[i][0..3]: column i of A, for the contraction down the rows
     T skj[4];  // SK[j][0..3]: column j of A, for the contractions along the row
@@ -86,6 +134,15 @@ template <typename T> ILQR_DEV void tile16_load(Tile16<T>& tl, const T* __restri
     tl.vj[0] = v.x; tl.vj[1] = v.y; tl.vj[2] = v.z; tl.vj[3] = v.w;
     tl.lxx = tp[16 + l16];
     tl.bi = tp[32 + 4 * i];
+}
+
+template <typename T>
+ILQR_DEV void tile16_load_buf(Tile16<T>& tl, __amdgpu_buffer_rsrc_t r, const TileOffsets& o, int soff) {
+    BufLoad<0, T>::v4(r, o.vi, soff, tl.ski);      // SK[i][0..3]
+    BufLoad<0, T>::v4(r, o.vj, soff, tl.skj);      // SK[j][0..3]
+    BufLoad<32, T>::v4(r, o.vj, soff, tl.vj);      // f_u[j], l_x[j], l_ux[j], e_j
+    tl.lxx = BufLoad<16, T>::v1(r, o.vl, soff);    // l_xx[i][j]
+    tl.bi = BufLoad<32, T>::v1(r, o.vi, soff);     // f_u[i]
 }
 
 // contraction along the matrix row: sum_d skj[d] * w[(j + d) % 4]
@@ -207,11 +264,20 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     const int N = a.N;
     T V = a.term[(size_t)(4 + l16) * B + b];
     T vx = a.term[(size_t)j * B + b];
-    const T* __restrict__ lin = a.lin + (size_t)b * kTile16;
-    const size_t tstride = B * kTile16;
-    T* __restrict__ rec = a.gains + (size_t)b * R + (i == 0 ? j : 4);
+    // buffer descriptors over the whole expansion / gain tensors (host guarantees both are < 2 GiB,
+    // otherwise it launches the flat-addressed LDS-ring variant)
+    const unsigned lin_bytes = (unsigned)((size_t)N * B * kTile16 * sizeof(T));
+    const unsigned gain_bytes = (unsigned)((size_t)N * B * R * sizeof(T));
+    const __amdgpu_buffer_rsrc_t rlin = make_rsrc(a.lin, lin_bytes);
+    const __amdgpu_buffer_rsrc_t rgain = make_rsrc(a.gains, gain_bytes);
+    const int tstride = (int)(B * kTile16 * sizeof(T));  // bytes between consecutive time steps
+    const int rstride = (int)(B * R * sizeof(T));
+    TileOffsets off;
+    off.vi = (int)((b * kTile16 + 4 * i) * sizeof(T));
+    off.vj = (int)((b * kTile16 + 4 * j) * sizeof(T));
+    off.vl = (int)((b * kTile16 + l16) * sizeof(T));
+    const int rec_off = (int)((b * R + (i == 0 ? j : 4)) * sizeof(T));
     const bool storer = act && (i == 0 || l16 == 4);
-    const size_t rstride = B * R;
     bool all_pd = true;
     LaneConst<T> lc;
     lc.m0 = T(j == 0);
@@ -223,20 +289,20 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
         bool pd;
         tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
         all_pd = all_pd && pd;
-        if (storer) rec[(size_t)t * rstride] = (i == 0) ? Kj : kff;
+        if (storer) buf_store1(rgain, rec_off, uniform(t * rstride), (i == 0) ? Kj : kff);
     };
 
     int t = N - 1;
     // remainder steps first (no ring), so that the pipelined loop runs whole rings only
     for (int r = N % D; r > 0; --r, --t) {
         Tile16<T> c;
-        tile16_load(c, lin + (size_t)t * tstride, i, j, l16);
+        tile16_load_buf(c, rlin, off, uniform(t * tstride));
         do_step(c, t);
     }
     if (t >= 0) {
         Tile16<T> ring[D];
 #pragma unroll
-        for (int u = 0; u < D; ++u) tile16_load(ring[u], lin + (size_t)(t - u) * tstride, i, j, l16);
+        for (int u = 0; u < D; ++u) tile16_load_buf(ring[u], rlin, off, uniform((t - u) * tstride));
         for (; t >= 0; t -= D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
@@ -246,7 +312,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
                 // branch-free and D-1 tiles per lane stay in flight.
                 do_step(ring[u], t - u);
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
-                tile16_load(ring[u], lin + (size_t)tn * tstride, i, j, l16);
+                tile16_load_buf(ring[u], rlin, off, uniform(tn * tstride));
             }
         }
     }

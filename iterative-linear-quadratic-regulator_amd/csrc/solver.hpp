@@ -109,7 +109,9 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
         // one wave = 4 trajectories x 16 lanes; 1024 single-wave workgroups at B = 4096 = one per SIMD
         o.backward = [](const KArgs<T>& a, hipStream_t s) {
             static const bool lds_ring = getenv("ILQR_BACKWARD_LDS_RING") != nullptr;  // A/B switch for profiling
-            if (lds_ring) {
+            // the register-ring kernel addresses both tensors through 32-bit buffer offsets
+            const bool fits = (size_t)a.N * a.B * kTile16 * sizeof(T) < (1ull << 31);
+            if (lds_ring || !fits) {
                 const dim3 grid((a.B + 3) / 4), block(64);
                 if (a.mu != T(0)) hipLaunchKernelGGL((backward_tile16_lds_kernel<T, true>), grid, block, 0, s, a);
                 else hipLaunchKernelGGL((backward_tile16_lds_kernel<T, false>), grid, block, 0, s, a);
