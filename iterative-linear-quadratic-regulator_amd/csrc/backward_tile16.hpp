@@ -160,18 +160,6 @@ template <typename T> ILQR_DEV T quad_sum(T v) {
     return v;
 }
 
-// reciprocal = hardware estimate + Newton steps (1 for float, 2 for double): ~1 ulp, 3-5 instructions
-// instead of the ~10-15 of the IEEE division sequence; Q_uu is a well-scaled positive number here.
-ILQR_DEV float fast_rcp(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
-    return fmaf(fmaf(-x, r, 1.0f), r, r);
-}
-ILQR_DEV double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return fma(fma(-x, r, 1.0), r, r);
-}
-
 // lane (i, j) <- lane (j, i) of the same 16-lane row: the 4x4 transpose is neither quad-local nor a
 // row rotation, so it goes through the LDS crossbar (ds_bpermute: one instruction, no LDS memory).
 ILQR_DEV float lane_transpose(float v, int src_byte) {

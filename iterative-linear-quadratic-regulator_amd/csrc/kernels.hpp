@@ -75,7 +75,7 @@ namespace ilqr {
 // sequential scan because it does not depend on the carry.
 // ---------------------------------------------------------------------------
 template <typename T, typename Dyn, bool TILE16, int INTEG>
-__global__ void __launch_bounds__(256) linearize_kernel(KArgs<T> a) {
+__global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
@@ -83,55 +83,80 @@ __global__ void __launch_bounds__(256) linearize_kernel(KArgs<T> a) {
     const size_t B = a.B;
     const int t = (int)(idx / B);
     const int b = (int)(idx % B);
-    if (t > a.N) return;
-    if (!traj_active(a.status[b])) return;
-    const int slot = a.cur_slot[b];
+    const bool live = t <= a.N && traj_active(a.status[b]);
+    if constexpr (!TILE16) {
+        if (!live) return;
+    }
     const T* __restrict__ p = a.params;
     T x[NX], u[NU];
-    const T* Xp = a.X + (((size_t)slot * (a.N + 1) + t) * NX) * B + b;
+    int slot = 0;
+    if (live) slot = a.cur_slot[b];
+    const int tt = live ? t : 0;
+    const int bb = live ? b : 0;
+    const T* Xp = a.X + (((size_t)slot * (a.N + 1) + tt) * NX) * B + bb;
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = Xp[(size_t)i * B];
-    if (t == a.N) {
+    if (live && t == a.N) {
         T g[NX];
         Cost<T, Dyn>::l_f_x(p, x, g);
 #pragma unroll
         for (int i = 0; i < NX; ++i) a.term[(size_t)i * B + b] = g[i];
 #pragma unroll
         for (int i = 0; i < NX * NX; ++i) a.term[(size_t)(NX + i) * B + b] = p[PL::QFS + i];
-        return;
+        if constexpr (!TILE16) return;
     }
-    const T* Up = a.U + (((size_t)slot * a.N + t) * NU) * B + b;
+    const bool point = live && t < a.N;   // this lane produces an expansion record
+    const int tu = point ? t : 0;
+    const T* Up = a.U + (((size_t)slot * a.N + tu) * NU) * B + bb;
 #pragma unroll
     for (int i = 0; i < NU; ++i) u[i] = Up[(size_t)i * B];
     T xn[NX], fx[NX][NX], fu[NX][NU];
     Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);  // integrator folded at compile time
     if constexpr (TILE16) {
-        // n_x = 4, n_u = 1: pack the 46 scalars into the 48-scalar tile of backward_tile16.hpp
+        // n_x = 4, n_u = 1: pack the 46 scalars into the 48-scalar tile of backward_tile16.hpp.  The 64
+        // tiles of a wave are contiguous in HBM (tile index = t*B + b = this lane's global index), but each
+        // lane holds ITS tile: a direct store would be 12 x 16-B pieces at a 192/384-B lane stride
+        // (measured 1.34x write amplification).  So the wave transposes through LDS in chunks and writes
+        // 16 B per lane to consecutive addresses.
         static_assert(NX == 4 && NU == 1, "tile packing is for n_x = 4, n_u = 1");
         using V4 = typename Vec4<T>::type;
         T gx[NX], gu1[NU];
         Cost<T, Dyn>::l_x(p, a.dt, x, gx);
         Cost<T, Dyn>::l_u(p, a.dt, u, gu1);
-        V4* out4 = reinterpret_cast<V4*>(a.lin + ((size_t)t * B + b) * kTile16);
+        V4 tile[12];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            V4 v;
-            v.x = fx[(c + 0) & 3][c]; v.y = fx[(c + 1) & 3][c]; v.z = fx[(c + 2) & 3][c]; v.w = fx[(c + 3) & 3][c];
-            out4[c] = v;
+            tile[c].x = fx[(c + 0) & 3][c]; tile[c].y = fx[(c + 1) & 3][c];
+            tile[c].z = fx[(c + 2) & 3][c]; tile[c].w = fx[(c + 3) & 3][c];
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            V4 v;
-            v.x = p[PL::QS + 4 * i + 0] * a.dt; v.y = p[PL::QS + 4 * i + 1] * a.dt;
-            v.z = p[PL::QS + 4 * i + 2] * a.dt; v.w = p[PL::QS + 4 * i + 3] * a.dt;
-            out4[4 + i] = v;
+            tile[4 + i].x = p[PL::QS + 4 * i + 0] * a.dt; tile[4 + i].y = p[PL::QS + 4 * i + 1] * a.dt;
+            tile[4 + i].z = p[PL::QS + 4 * i + 2] * a.dt; tile[4 + i].w = p[PL::QS + 4 * i + 3] * a.dt;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            V4 v;
-            v.x = fu[j][0]; v.y = gx[j]; v.z = T(0);
-            v.w = (j == 0) ? gu1[0] : ((j == 1) ? p[PL::RS] * a.dt : T(0));
-            out4[8 + j] = v;
+            tile[8 + j].x = fu[j][0]; tile[8 + j].y = gx[j]; tile[8 + j].z = T(0);
+            tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? p[PL::RS] * a.dt : T(0));
+        }
+        constexpr int CH = sizeof(T) == 4 ? 12 : 6;   // V4s per lane per chunk (keeps LDS at ~14 KB per wave)
+        constexpr int ROW = CH + 1;                   // padded row: conflict-free 16-B-per-lane writes
+        __shared__ V4 xpose[64 * ROW];
+        const int lane = threadIdx.x;
+        const unsigned long long okmask = __ballot(point);
+        V4* gout = reinterpret_cast<V4*>(a.lin) + (size_t)blockIdx.x * 64 * 12;   // first tile of this wave
+#pragma unroll
+        for (int c = 0; c < 12 / CH; ++c) {
+            if (c) __syncthreads();
+#pragma unroll
+            for (int q = 0; q < CH; ++q) xpose[lane * ROW + q] = tile[c * CH + q];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const int v = lane + 64 * r;          // v-th V4 of this chunk, tile-major
+                const int k = v / CH, q = v % CH;
+                if ((okmask >> k) & 1ull) gout[(size_t)k * 12 + c * CH + q] = xpose[k * ROW + q];
+            }
         }
         return;
     }
@@ -452,7 +477,10 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     T* Uc = a.U + ((size_t)cslot * N * NU) * B + b;
     // The per-step inputs (x_old, u_old, K, k) do not depend on the carried state, so step t+1's are
     // requested before step t's arithmetic starts: their latency hides under one RK4 step.
-    T xo[NX], uo[NU], g[R], xo_n[NX], uo_n[NU], g_n[R];
+    // (for big gain records, n_x > 4, the double buffer would not fit the register file: load in place)
+    constexpr bool PREFETCH = (R <= 32);
+    constexpr int RN = PREFETCH ? R : 1, NXN = PREFETCH ? NX : 1, NUN = PREFETCH ? NU : 1;
+    T xo[NX], uo[NU], g[R], xo_n[NXN], uo_n[NUN], g_n[RN];
 #pragma unroll
     for (int i = 0; i < NX; ++i) xo[i] = Xo[(size_t)i * B];
 #pragma unroll
@@ -461,12 +489,14 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     for (int r = 0; r < R; ++r) g[r] = G[r];
     for (int t = 0; t < N; ++t) {
         const int tn = (t + 1 < N) ? t + 1 : t;
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xo_n[i] = Xo[((size_t)tn * NX + i) * B];
+            for (int i = 0; i < NX; ++i) xo_n[i] = Xo[((size_t)tn * NX + i) * B];
 #pragma unroll
-        for (int j = 0; j < NU; ++j) uo_n[j] = Uo[((size_t)tn * NU + j) * B];
+            for (int j = 0; j < NU; ++j) uo_n[j] = Uo[((size_t)tn * NU + j) * B];
 #pragma unroll
-        for (int r = 0; r < R; ++r) g_n[r] = G[(size_t)tn * B * R + r];
+            for (int r = 0; r < R; ++r) g_n[r] = G[(size_t)tn * B * R + r];
+        }
         T dx[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
@@ -486,11 +516,22 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
         T xn[NX];
         Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);  // integrator folded at compile time
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { x[i] = xn[i]; xo[i] = xo_n[i]; }
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+        if constexpr (PREFETCH) {
 #pragma unroll
-        for (int j = 0; j < NU; ++j) uo[j] = uo_n[j];
+            for (int i = 0; i < NX; ++i) xo[i] = xo_n[i];
 #pragma unroll
-        for (int r = 0; r < R; ++r) g[r] = g_n[r];
+            for (int j = 0; j < NU; ++j) uo[j] = uo_n[j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) g[r] = g_n[r];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xo[i] = Xo[((size_t)tn * NX + i) * B];
+#pragma unroll
+            for (int j = 0; j < NU; ++j) uo[j] = Uo[((size_t)tn * NU + j) * B];
+#pragma unroll
+            for (int r = 0; r < R; ++r) g[r] = G[(size_t)tn * B * R + r];
+        }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
@@ -565,6 +606,9 @@ __global__ void __launch_bounds__(256) select_kernel(KArgs<T> a) {
     if (a.last_pass || a.init_mode) {
         const unsigned long long m = __ballot(still_active);
         if ((threadIdx.x & 63) == 0 && m) atomicAdd(&a.counters[a.counter_idx], (int)__popcll(m));
+        // the next iteration's counter is cleared here (stream order makes it safe), so the host loop
+        // needs no memset launch per iteration
+        if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[(a.counter_idx + 1) % kCounterRing] = 0;
     }
 }
 

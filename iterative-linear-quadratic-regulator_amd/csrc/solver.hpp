@@ -17,7 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "kernels.hpp"
+#include "kernels_wave.hpp"
 
 namespace ilqr {
 
@@ -77,6 +77,7 @@ template <typename T> struct Ops {
     int n_sys_dev = 0;
     int lin_stride = 0;   // scalars per (b, t) in the expansion buffer
     bool tile16 = false;  // expansion packed as 48-scalar tiles (n_x = 4, n_u = 1)
+    bool lin_aos = false; // expansion stored as [N][B][E] records (n_x > 4, wave-cooperative kernels)
 };
 
 // linearize / forward are compiled once per integrator so the integrator switch folds away and each
@@ -87,7 +88,8 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
     constexpr int I = (SMALL || INTEG == ILQR_INT_DISCRETE) ? INTEG : ILQR_INT_EULER;
     o.linearize[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
         const size_t total = (size_t)a.B * (a.N + 1);
-        hipLaunchKernelGGL((linearize_kernel<T, Dyn, TILE, I>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+        constexpr int TPB = TILE ? 64 : 256;
+        hipLaunchKernelGGL((linearize_kernel<T, Dyn, TILE, I>), dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, s, a);
     };
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
         hipLaunchKernelGGL((forward_kernel<T, Dyn, I>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
@@ -136,6 +138,38 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
             hipLaunchKernelGGL((backward_lane_kernel<T, NX, NU>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
         };
     }
+    o.eval = [](const EvalArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((eval_points_kernel<T, Dyn>), dim3((a.npts + 63) / 64), dim3(64), 0, s, a);
+    };
+    o.mpc_advance = [](const MpcArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((mpc_advance_kernel<T, Dyn>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+    };
+    o.n_dev_params = ParamLayout<Dyn::NSYS, NX, NU>::TOTAL;
+    o.n_sys_dev = Dyn::NSYS;
+    return o;
+}
+
+// n_x > 4 (linear systems): wave-cooperative linearise / backward, generic lane-per-rollout forward
+template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
+    using Dyn = Linear<T, NX, NU>;
+    Ops<T> o;
+    o.lin_aos = true;
+    o.lin_stride = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+    for (int k = 0; k < 5; ++k) {
+        o.linearize[k] = [](const KArgs<T>& a, hipStream_t s) {
+            hipLaunchKernelGGL((linearize_wave_kernel<T, NX, NU>), dim3((unsigned)((size_t)a.B * (a.N + 1))), dim3(64), 0, s, a);
+        };
+    }
+    o.forward[ILQR_INT_EULER] = [](const KArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((forward_kernel<T, Dyn, ILQR_INT_EULER>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+    };
+    o.forward[ILQR_INT_DISCRETE] = [](const KArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((forward_kernel<T, Dyn, ILQR_INT_DISCRETE>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+    };
+    o.forward[ILQR_INT_MIDPOINT] = o.forward[ILQR_INT_RK4] = o.forward[ILQR_INT_BACKWARD_EULER] = o.forward[ILQR_INT_EULER];
+    o.backward = [](const KArgs<T>& a, hipStream_t s) {
+        hipLaunchKernelGGL((backward_wave_kernel<T, NX, NU>), dim3(a.B), dim3(64), 0, s, a);
+    };
     o.eval = [](const EvalArgs<T>& a, hipStream_t s) {
         hipLaunchKernelGGL((eval_points_kernel<T, Dyn>), dim3((a.npts + 63) / 64), dim3(64), 0, s, a);
     };
@@ -441,6 +475,13 @@ template <typename T> class SolverT : public SolverBase {
         return check_launch();
     }
     int down_lin(void* host, const T* lin) {
+        if (ops.lin_aos) {
+            const size_t n = (size_t)B * N * E;
+            hipLaunchKernelGGL(gains_gather_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, E, E);
+            ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
+            ILQR_HIPCHK(hipStreamSynchronize(stream));
+            return check_launch();
+        }
         if (!ops.tile16) return down_tc(host, lin, E, N);
         const size_t n = (size_t)B * N * E;
         hipLaunchKernelGGL(tile16_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
@@ -618,8 +659,7 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = do_linearize(st))) return rc;
         if ((rc = do_backward(st))) return rc;
         const int total = (int)trial_alphas.size();
-        const int cidx = next_counter();
-        ILQR_HIPCHK(hipMemsetAsync(st.counters + cidx, 0, sizeof(int), stream));
+        const int cidx = next_counter();  // cleared by the previous select launch
         for (int base = 0; base < total; base += A) {
             const int n = std::min(A, total - base);
             const bool last = (base + n >= total);

@@ -186,3 +186,158 @@ def test_fp32_mode_error_is_bounded():
                                    U[b].astype(np.float32).astype(np.float64))
         np.testing.assert_allclose(K[b], K_o, rtol=2e-3, atol=2e-3 * np.abs(K_o).max())
         np.testing.assert_allclose(uff[b], uff_o, rtol=2e-3, atol=2e-3 * np.abs(uff_o).max())
+
+
+# ---- config c5: synthetic linear-quadratic system on the wave-cooperative kernels (n_x > 4) --------------
+@pytest.mark.parametrize("n,m,N", [(16, 8, 60), (8, 4, 33)])
+def test_linear_quadratic_wave_kernels_match_oracle(n, m, N):
+    p = problems.linear_quadratic(n=n, m=m, N=N)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    B = 3
+    x0, U0 = problems.lq_batch(B, n, m, N)
+    rng = np.random.default_rng(4)
+    X, U = rng.standard_normal((B, n, N + 1)), rng.standard_normal((B, m, N))
+    s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=1e-9, maxiter=4, verbose=False)
+    uff, K = s.backward_pass(X, U)
+    for b in range(B):
+        uff_o, K_o = backward_pass(orc, X[b], U[b])
+        np.testing.assert_allclose(K[b], K_o, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(uff[b], uff_o, rtol=RTOL, atol=1e-9)
+    Xs, Us, cost = s.optimize_trajectory()
+    for b in range(B):
+        o = iLQROracle(orc, N=N, x_0=x0[b], U_init=U0[b], tol=1e-9, maxiter=4)
+        Xo, Uo, co = o.optimize_trajectory()
+        np.testing.assert_allclose(cost[b], co, rtol=RTOL)
+        np.testing.assert_allclose(Us[b], Uo, rtol=1e-5, atol=1e-8)
+        assert o.history[0][1] == 1.0   # LQ: the full step is accepted and is optimal
+    # known answer: iLQR gains of an LQ problem = finite-horizon discrete Riccati recursion
+    A, Bm, dt = p["dynamics"]["A"], p["dynamics"]["B"], p["dynamics"]["dt"]
+    Q, R, P = p["cost"]["Q"] * dt, p["cost"]["R"] * dt, p["cost"]["Q_f"].copy()
+    Kd = s.K
+    for t in range(N - 1, -1, -1):
+        Kt = -np.linalg.solve(R + Bm.T @ P @ Bm, Bm.T @ P @ A)
+        np.testing.assert_allclose(Kd[0, t], Kt, rtol=1e-6, atol=1e-10)
+        P = Q + A.T @ P @ A + A.T @ P @ Bm @ Kt
+
+
+@pytest.mark.parametrize("name", ["ua", "dp", "lq16"])
+def test_levenberg_regularisation_matches_oracle(name):
+    """mu > 0 (the build's extension): K = -(Q_uu + mu I)^-1 Q_ux with the full value update."""
+    if name == "lq16":
+        p = problems.linear_quadratic(n=16, m=8, N=25)
+    else:
+        p = _specs()[name]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    N, B, mu = p["N"], 2, 0.37
+    X, U = _rand_traj(sysm.n_x, sysm.n_u, N, B, seed=8, scale=0.5)
+    s = ilqr_amd.iLQR(sysm, None, X[:, :, 0], U, N=N, verbose=False, mu=mu)
+    uff, K = s.backward_pass(X, U)
+    for b in range(B):
+        uff_o, K_o = backward_pass(orc, X[b], U[b], mu=mu)
+        np.testing.assert_allclose(K[b], K_o, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(uff[b], uff_o, rtol=RTOL, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,N", [(1, 7), (5, 13), (17, 41), (67, 9)])
+def test_ragged_batch_and_horizon_sizes(B, N):
+    """Batch not a multiple of 4 / 16 / 64 and horizon not a multiple of the prefetch ring."""
+    p = problems.ua_double_pendulum(N=N)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    orc = oracle_from_system(sysm)
+    x0, U0 = problems.ua_batch(B, seed=B, restarts=True, N=N)
+    s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=1e-5, maxiter=3, verbose=False)
+    X, U, cost = s.optimize_trajectory()
+    for b in sorted({0, B // 2, B - 1}):
+        o = iLQROracle(orc, N=N, x_0=x0[b], U_init=U0[b], tol=1e-5, maxiter=3)
+        _, Uo, co = o.optimize_trajectory()
+        np.testing.assert_allclose(cost[b], co, rtol=RTOL)
+        np.testing.assert_allclose(s.K[b], o.K, rtol=1e-4, atol=1e-7)
+
+
+def test_finished_trajectories_are_frozen():
+    """A trajectory that converged (or failed its line search) keeps X, U, K, cost while the rest of
+    the batch goes on iterating (the reference's `break`, iLQR_class.py:267-271, 304-307)."""
+    p = problems.ua_double_pendulum(N=50)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    B = 8
+    x0, U0 = problems.ua_batch(B, seed=5, restarts=True, N=50)
+    x0 = x0 * np.linspace(0.0, 3.0, B)[:, None]          # from "already at rest" to strongly perturbed
+    s = ilqr_amd.iLQR(sysm, None, x0, U0, N=50, tol=0.5, maxiter=25, verbose=False)
+    s.optimize_trajectory()
+    it = np.asarray(s.iterations)
+    orc = oracle_from_system(sysm)
+    its_o = []
+    for b in range(B):
+        o = iLQROracle(orc, N=50, x_0=x0[b], U_init=U0[b], tol=0.5, maxiter=25)
+        _, _, co = o.optimize_trajectory()
+        its_o.append(o.iterations)
+        assert int(it[b]) == o.iterations and s.status[b] == o.status
+        np.testing.assert_allclose(s.cost[b], co, rtol=RTOL)
+    assert min(its_o) < max(its_o)      # the batch really did stop at different iterations
+
+
+def test_golden_fixtures_on_device():
+    """The committed golden vectors (tests/golden/*.npz, generator committed) through the C-ABI."""
+    import glob
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    base = {"c1": problems.pendulum_open_loop(), "c2": problems.ua_double_pendulum(), "dp": problems.double_pendulum()}
+    for path in sorted(glob.glob(os.path.join(gold, "c*_*.npz")) + glob.glob(os.path.join(gold, "dp_*.npz"))):
+        g = np.load(path)
+        b0 = base[os.path.basename(path).split("_")[0]]
+        sysm = ilqr_amd.make_system(dict(b0["dynamics"], integrator=str(g["integrator"])), b0["cost"])
+        N = int(g["N"])
+        s = ilqr_amd.iLQR(sysm, None, g["x0"], g["U_init"], N=N, tol=float(g["tol"]), maxiter=int(g["maxiter"]),
+                          verbose=False)
+        uff, K = s.backward_pass(g["rollout_X"], g["rollout_U"])
+        np.testing.assert_allclose(K, g["first_K"], rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(uff, g["first_Uff"], rtol=RTOL, atol=1e-9)
+        X, U, cost = s.optimize_trajectory()
+        np.testing.assert_allclose(cost, g["cost"], rtol=RTOL)
+        assert list(s.status) == [str(x) for x in g["status"]]
+        assert np.array_equal(np.asarray(s.iterations), g["iterations"])
+    g = np.load(os.path.join(gold, "mpc_pendulum.npz"))
+    p = problems.pendulum_mpc(N=int(g["N"]))
+    st = ilqr_amd.mpc_init(p["dynamics"], p["cost"], p["x0"], p["U_init"], plant_integrator="midpoint",
+                           N=int(g["N"]), tol=p["tol"], maxiter=p["maxiter"])
+    U_sim, X_sim, costs = st.solver.mpc_run(int(g["n_sim"]))
+    np.testing.assert_allclose(costs, g["cost"], rtol=RTOL)
+    np.testing.assert_allclose(U_sim, g["U_sim"].T, rtol=1e-5, atol=1e-8)
+
+
+def test_full_size_properties_c3():
+    """BASELINE size (B = 4096, N = 200), where the NumPy oracle is too slow to run everything:
+    size-independent properties -- (1) sampled trajectories agree with the C oracle; (2) costs never
+    increase over iterations (acceptance rule); (3) the full-size backward sweep is bit-reproducible and
+    matches the C oracle on sampled trajectories."""
+    from oracle.c_oracle import COracle
+    p = problems.ua_double_pendulum()
+    B, N = 4096, 200
+    x0, U0 = problems.ua_batch(B, seed=1000)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=1e-5, maxiter=6, verbose=False)
+    h = s.handle
+    h.initial_rollout()
+    prev = h.get(_lib.COST)
+    for _ in range(6):
+        h.iterate(1)
+        c = h.get(_lib.COST)
+        assert np.all(c <= prev)
+        prev = c
+    co = COracle(p["dynamics"], p["cost"])
+    for b in (0, 1234, 4095):
+        r = co.solve(x0[b], U0[b], tol=1e-5, maxiter=6)
+        np.testing.assert_allclose(prev[b], r["cost"], rtol=RTOL)
+    # (3) backward sweep around the final trajectories at full size: bit-identical when repeated
+    # (deterministic, no atomics), and equal to the C oracle on sampled trajectories
+    X, U = h.get(_lib.X), h.get(_lib.U)
+    uff_a, K_a = s.backward_pass(X, U)
+    uff_b, K_b = s.backward_pass(X, U)
+    assert np.array_equal(K_a, K_b) and np.array_equal(uff_a, uff_b)
+    assert np.isfinite(K_a).all()
+    for b in (0, 1234, 4095):
+        uff_o, K_o = co.backward_pass(X[b], U[b])
+        np.testing.assert_allclose(K_a[b], K_o, rtol=RTOL, atol=1e-9)
+        np.testing.assert_allclose(uff_a[b], uff_o, rtol=RTOL, atol=1e-9)
