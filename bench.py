@@ -110,7 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
     ap.add_argument("--n-alpha", type=int, default=10)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", default="f32", choices=["f64", "f32"],
+                    help="f32 = the reference's own (JAX default) precision; f64 = the build's double mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true")
     args = ap.parse_args()
@@ -144,8 +145,13 @@ def main():
     B, N = args.batch, p["N"]
     x0, U0 = problems.ua_batch(B, seed=1000 + rank, restarts=False, N=N)
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
-    # launch on torch's current stream so barriers / synchronize / events see the kernels
-    stream = torch.cuda.current_stream().cuda_stream
+    # launch on an explicit torch stream (made current) so torch's barriers, synchronize() and events see
+    # the kernels: torch.cuda.Event only observes torch's current stream, and a NULL stream pointer would
+    # make the handle create a private one
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream, "expected a non-null HIP stream from torch"
     h = sysm.make_handle(horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=1 << 30,
                          device=local_rank, flags=_lib.FLAG_KEEP_ITERATING, stream=stream)
     h.set_problem(x0, U0)       # uploads: inputs are HBM-resident from here on
@@ -167,16 +173,39 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    if not args.no_phase_timing:
-        h.timing_enable(True)
-        h.timing_reset()
+    # ---- the timed region: exactly K steps, nothing else on the stream ------------------------------
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     wall = time.perf_counter() - t0
-    phases = h.timing_get() if not args.no_phase_timing else None
-    h.timing_enable(False)
+
+    # ---- per-phase breakdown: the same K steps again with HIP start/stop events attached to every kernel
+    # dispatch (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, no extra stream packets)
+    phases = None
+    bwd_us = None
+    if not args.no_phase_timing:
+        h.timing_enable(True)
+        h.timing_reset()
+        for _ in range(args.steps):
+            h.iterate(1)
+        phases = h.timing_get()
+        h.timing_enable(False)
+        # ---- extra: R back-to-back launches of the backward sweep on the same expansion (idempotent: reads
+        # lin/term, rewrites the same gains) between ONE pair of torch events on this stream.  It runs
+        # faster than inside the iteration (its tiles are then still cached from the previous launch instead
+        # of being freshly written by linearise) and is reported separately, not used for the roofline.
+        R = 50
+        h.linearize()
+        for _ in range(5):
+            h.backward()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(R):
+            h.backward()
+        e1.record()
+        torch.cuda.synchronize()
+        bwd_us = e0.elapsed_time(e1) * 1e3 / R
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -203,7 +232,7 @@ def main():
         if phases is not None:
             ab = h.algorithmic_bytes()
             ms, n = phases["backward"]
-            avg_s = ms / max(n, 1) * 1e-3
+            avg_s = ms / max(n, 1) * 1e-3      # in-iteration launches of the profiled K steps
             achieved = ab["backward"] / avg_s / 1e9
             tr = pmc_traffic(args.dtype, B, N)
             out["roofline"] = {"bound": "hbm", "kernel": "backward Riccati sweep (backward_tile16_kernel)",
@@ -211,7 +240,8 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
                                "traffic_source": tr[1] if tr else None,
                                "algorithmic_bytes_per_launch": ab["backward"], "avg_launch_us": avg_s * 1e6,
-                               "launches": n, "frac_of_measured_copy_peak_6.29TBs": achieved / 6290.0}
+                               "launches": n, "avg_launch_us_back_to_back": bwd_us,
+                               "frac_of_measured_copy_peak_6.29TBs": achieved / 6290.0}
             out["phases_us_per_step"] = {k: 1e3 * v[0] / args.steps for k, v in phases.items()}
         if os.environ.get("ILQR_CLOCK_PROBE"):
             pr = h.get(_lib.PROBE)

@@ -145,12 +145,49 @@ ILQR_DEV void tile16_load_buf(Tile16<T>& tl, __amdgpu_buffer_rsrc_t r, const Til
     tl.bi = BufLoad<32, T>::v1(r, o.vi, soff);     // f_u[i]
 }
 
+// acc += coef * (w moved across lanes by a DPP pattern), as ONE instruction (v_fmac_f32_dpp).  hipcc's
+// DPP combiner folds a lane move into v_mul / v_add but not into the accumulating v_fmac (tied operand), so
+// each contraction term cost a v_mov_b32_dpp plus a v_fmac; the fused form is written in asm.  The asm is
+// opaque to hipcc's hazard padding (cdna_hip_programming.md 5.7 item 2): a VGPR written by a VALU needs 2
+// wait states before a DPP read, hence the s_nop 1 inside every statement (it replaces the s_nop hipcc
+// put in front of the v_mov_b32_dpp anyway).
+#define ILQR_FMAC_DPP_(NOP, acc, w, coef, CTRL)                                                        \
+    asm volatile(NOP "v_fmac_f32_dpp %0, %1, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1"        \
+                 : "+v"(acc)                                                                           \
+                 : "v"(w), "v"(coef))
+// first use of a freshly written operand carries the 2 wait states; the next statements on the SAME operand
+// follow it in program order (volatile asm statements are not reordered among themselves) and need none
+#define ILQR_FMAC_DPP_FIRST(acc, w, coef, CTRL) ILQR_FMAC_DPP_("s_nop 1\n\t", acc, w, coef, CTRL)
+#define ILQR_FMAC_DPP_NEXT(acc, w, coef, CTRL) ILQR_FMAC_DPP_("", acc, w, coef, CTRL)
+
 // contraction along the matrix row: sum_d skj[d] * w[(j + d) % 4]
-template <typename T> ILQR_DEV T contract_row(const T* skj, T w) {
-    T acc = skj[0] * w;
+ILQR_DEV float contract_row(const float* skj, float w, float init) {
+    float acc = fmaf(skj[0], w, init);
+    ILQR_FMAC_DPP_FIRST(acc, w, skj[1], "quad_perm:[1,2,3,0]");
+    ILQR_FMAC_DPP_NEXT(acc, w, skj[2], "quad_perm:[2,3,0,1]");
+    ILQR_FMAC_DPP_NEXT(acc, w, skj[3], "quad_perm:[3,0,1,2]");
+    return acc;
+}
+ILQR_DEV double contract_row(const double* skj, double w, double init) {
+    double acc = fma(skj[0], w, init);
     acc += skj[1] * dpp<kRight1>(w);
     acc += skj[2] * dpp<kRight2>(w);
     acc += skj[3] * dpp<kRight3>(w);
+    return acc;
+}
+// contraction down the matrix column: sum_d ski[d] * w[(i + d) % 4]
+ILQR_DEV float contract_col(const float* ski, float w) {
+    float acc = ski[0] * w;
+    ILQR_FMAC_DPP_FIRST(acc, w, ski[1], "row_ror:12");
+    ILQR_FMAC_DPP_NEXT(acc, w, ski[2], "row_ror:8");
+    ILQR_FMAC_DPP_NEXT(acc, w, ski[3], "row_ror:4");
+    return acc;
+}
+ILQR_DEV double contract_col(const double* ski, double w) {
+    double acc = ski[0] * w;
+    acc += ski[1] * dpp<kDown1>(w);
+    acc += ski[2] * dpp<kDown2>(w);
+    acc += ski[3] * dpp<kDown3>(w);
     return acc;
 }
 // sum over the 4 lanes of a quad, result in every lane of the quad
@@ -174,10 +211,19 @@ ILQR_DEV double lane_transpose(double v, int src_byte) {
 // the two row contractions that share coefficients and rotation pattern (Q_ux from pu, Q_x from V_x).
 // (A packed v_pk_fma_f32 form of this pair was tried: hipcc assembled the register pairs through scratch
 // and the sweep ran 2.7x slower, so the two streams stay scalar.)
-template <typename T>
-ILQR_DEV void contract_row2(const T* skj, T w0, T w1, T c0, T c1, T& o0, T& o1) {
-    o0 = c0 + contract_row(skj, w0);
-    o1 = c1 + contract_row(skj, w1);
+ILQR_DEV void contract_row2(const float* skj, float w0, float w1, float c0, float c1, float& o0, float& o1) {
+    float a0 = fmaf(skj[0], w0, c0), a1 = fmaf(skj[0], w1, c1);
+    ILQR_FMAC_DPP_FIRST(a0, w0, skj[1], "quad_perm:[1,2,3,0]");
+    ILQR_FMAC_DPP_NEXT(a1, w1, skj[1], "quad_perm:[1,2,3,0]");
+    ILQR_FMAC_DPP_NEXT(a0, w0, skj[2], "quad_perm:[2,3,0,1]");
+    ILQR_FMAC_DPP_NEXT(a1, w1, skj[2], "quad_perm:[2,3,0,1]");
+    ILQR_FMAC_DPP_NEXT(a0, w0, skj[3], "quad_perm:[3,0,1,2]");
+    ILQR_FMAC_DPP_NEXT(a1, w1, skj[3], "quad_perm:[3,0,1,2]");
+    o0 = a0; o1 = a1;
+}
+ILQR_DEV void contract_row2(const double* skj, double w0, double w1, double c0, double c1, double& o0, double& o1) {
+    o0 = contract_row(skj, w0, c0);
+    o1 = contract_row(skj, w1, c1);
 }
 
 // per-lane constants of the sweep
@@ -192,10 +238,7 @@ template <typename T> struct LaneConst {
 template <typename T, bool REG>
 ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V, T& vx, T& Kj, T& kff, bool& pd) {
     // P = f_x' V_xx :  P[i][j] = sum_d A[(i+d)%4][i] * V[(i+d)%4][j]
-    T P = c.ski[0] * V;
-    P += c.ski[1] * dpp<kDown1>(V);
-    P += c.ski[2] * dpp<kDown2>(V);
-    P += c.ski[3] * dpp<kDown3>(V);
+    const T P = contract_col(c.ski, V);
     // pu = f_u' V_xx :  pu[j] = sum_i b[i] V[i][j]   (sum down the rows, result in every row)
     T pu = c.bi * V;
     pu += dpp<kDown2>(pu);
@@ -214,7 +257,7 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
     // Q_ux in "row form": lane (i, j) <- Q_ux[i], held by lane (j, i)
     const T Quxi = lane_transpose(Qux, lc.tr_byte);
     // Q_xx = l_xx + P f_x
-    const T Qxx = c.lxx + contract_row(c.skj, P);
+    const T Qxx = contract_row(c.skj, P, c.lxx);
     if constexpr (!REG) {
         // short form (:113-114): V_x = Q_x + K'Q_u ; V_xx = Q_xx + Q_ux' K
         V = Qxx + Quxi * Kj;
@@ -225,6 +268,65 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
         V = Qxx + Ki * (Quu * Kj) + Ki * Qux + Quxi * Kj;
         vx = Qx + Kj * (Quu * kff + Qu) + Qux * kff;
     }
+}
+
+// ---- fp32 step with a hand-ordered instruction stream ---------------------------------------------------
+// The three chains of a step -- (A) P -> Q_xx, (B) pu -> Q_ux, Q_uu, (C) Q_x, Q_u -- are independent until
+// the gain solve.  A lone wave issues an independent instruction every ~4 cycles but a dependent one only
+// every ~6.5-8, and a DPP read needs 2 wait states behind its producer; hipcc's order left the sweep at
+// ~6.5 cycles/instruction.  Here the first 27 instructions are volatile asm statements (never reordered
+// among themselves) written round-robin over the chains, so every operand was produced >= 3 instructions
+// earlier: no s_nop, no dependent-issue bubble.  The short serial tail (reciprocal, gains, transpose,
+// value update) stays in C++ where hipcc pads the transcendental / LDS-crossbar hazards itself.
+#define ILQR_V_MUL(d, a, b) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
+#define ILQR_V_FMA(d, a, b, c) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
+#define ILQR_V_FMAC(acc, a, b) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
+#define ILQR_V_ADD_DPP(d, a, CTRL)                                                              \
+    asm volatile("v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(a))
+#define ILQR_QP1 "quad_perm:[1,2,3,0]"
+#define ILQR_QP2 "quad_perm:[2,3,0,1]"
+#define ILQR_QP3 "quad_perm:[3,0,1,2]"
+#define ILQR_QSW "quad_perm:[1,0,3,2]"
+
+ILQR_DEV void tile16_step_f32(const Tile16<float>& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj,
+                              float& kff, bool& pd) {
+    float P, pu, qx, qu, quu, Qxx, Qux, t;
+    ILQR_V_MUL(P, c.ski[0], V);                               //  1 A
+    ILQR_V_MUL(pu, c.bi, V);                                  //  2 B
+    ILQR_V_FMA(qx, c.skj[0], vx, c.vj[1]);                    //  3 C   Q_x = l_x + ...
+    ILQR_FMAC_DPP_NEXT(P, V, c.ski[1], "row_ror:12");         //  4 A
+    ILQR_V_ADD_DPP(t, pu, "row_ror:8");                       //  5 B   pu[i] + pu[i+2]
+    ILQR_FMAC_DPP_NEXT(qx, vx, c.skj[1], ILQR_QP1);           //  6 C
+    ILQR_FMAC_DPP_NEXT(P, V, c.ski[2], "row_ror:8");          //  7 A
+    ILQR_V_MUL(qu, c.vj[0], vx);                              //  8 C2  f_u[j] * V_x[j]
+    ILQR_FMAC_DPP_NEXT(qx, vx, c.skj[2], ILQR_QP2);           //  9 C
+    ILQR_FMAC_DPP_NEXT(P, V, c.ski[3], "row_ror:4");          // 10 A   P done
+    ILQR_V_ADD_DPP(pu, t, "row_ror:12");                      // 11 B   pu done (sum over the 4 rows)
+    ILQR_FMAC_DPP_NEXT(qx, vx, c.skj[3], ILQR_QP3);           // 12 C   Q_x done
+    ILQR_V_FMAC(qu, lc.m0, c.vj[3]);                          // 13 C2  + l_u on lane j = 0
+    ILQR_V_FMA(Qxx, c.skj[0], P, c.lxx);                      // 14 A   Q_xx = l_xx + ...
+    ILQR_V_FMA(Qux, c.skj[0], pu, c.vj[2]);                   // 15 B   Q_ux = l_ux + ...
+    ILQR_V_MUL(quu, pu, c.vj[0]);                             // 16 B2  pu[j] * f_u[j]
+    ILQR_FMAC_DPP_NEXT(Qxx, P, c.skj[1], ILQR_QP1);           // 17 A
+    ILQR_FMAC_DPP_NEXT(Qux, pu, c.skj[1], ILQR_QP1);          // 18 B
+    ILQR_V_FMAC(quu, lc.m1, c.vj[3]);                         // 19 B2  + l_uu on lane j = 1
+    ILQR_V_ADD_DPP(t, qu, ILQR_QSW);                          // 20 C2
+    ILQR_FMAC_DPP_NEXT(Qxx, P, c.skj[2], ILQR_QP2);           // 21 A
+    ILQR_FMAC_DPP_NEXT(Qux, pu, c.skj[2], ILQR_QP2);          // 22 B
+    ILQR_V_ADD_DPP(quu, quu, ILQR_QSW);                       // 23 B2
+    ILQR_V_ADD_DPP(qu, t, ILQR_QP2);                          // 24 C2  Q_u done
+    ILQR_FMAC_DPP_NEXT(Qxx, P, c.skj[3], ILQR_QP3);           // 25 A   Q_xx done
+    ILQR_FMAC_DPP_NEXT(Qux, pu, c.skj[3], ILQR_QP3);          // 26 B   Q_ux done
+    ILQR_V_ADD_DPP(quu, quu, ILQR_QP2);                       // 27 B2  Q_uu done
+    pd = quu > 0.0f;
+    // Q_ux in row form (lane (i, j) <- Q_ux[i]) through the LDS crossbar.  (Four bank-masked DPP moves do
+    // the same with less latency but three more issue slots: measured 38.3 vs 36.6 us per workgroup.)
+    const float inv = fast_rcp(quu);
+    const float Quxi = lane_transpose(Qux, lc.tr_byte);
+    Kj = -(Qux * inv);
+    kff = -(qu * inv);
+    V = fmaf(Quxi, Kj, Qxx);
+    vx = fmaf(Kj, qu, qx);
 }
 
 // Workgroup = 4 waves = 16 trajectories, launched with > 80 KiB of (unused) dynamic LDS so that a CU
@@ -275,7 +377,8 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     auto do_step = [&](const Tile16<T>& c, int t) {
         T Kj, kff;
         bool pd;
-        tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
+        if constexpr (sizeof(T) == 4 && !REG) tile16_step_f32(c, lc, V, vx, Kj, kff, pd);
+        else tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
         all_pd = all_pd && pd;
         if (storer) buf_store1(rgain, rec_off, uniform(t * rstride), (i == 0) ? Kj : kff);
     };

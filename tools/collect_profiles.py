@@ -1,0 +1,43 @@
+"""Copies the judged summaries of a tools/gpu_profile.sh run from gpurun_out/prof (scratch) into
+profiles/rNN (tracked): bench JSON lines, rocprofv3 --kernel-trace --stats summaries, and the PMC
+traffic of the hot kernels (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)."""
+import csv, glob, json, os, shutil, sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src, dst = "gpurun_out/prof", os.path.join("profiles", rnd)
+os.makedirs(dst, exist_ok=True)
+for name, out in (("bench_default.json", "bench_default_f32.json"), ("bench_f64.json", "bench_f64.json")):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, out))
+for dt in ("f32", "f64"):
+    for f in glob.glob(f"{src}/trace_{dt}/*/*_kernel_stats.csv"):
+        shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_{dt}.csv"))
+    fetch = glob.glob(f"{src}/pmc_fetch_{dt}/*/*_counter_collection.csv")
+    write = glob.glob(f"{src}/pmc_write_{dt}/*/*_counter_collection.csv")
+    if not (fetch and write):
+        continue
+    shutil.copy(fetch[0], os.path.join(dst, f"rocprofv3_pmc_FETCH_SIZE_{dt}.csv"))
+    shutil.copy(write[0], os.path.join(dst, f"rocprofv3_pmc_WRITE_SIZE_{dt}.csv"))
+
+    def mean_counter(path, kern):
+        v = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kern in r["Kernel_Name"]]
+        return (sum(v) / len(v), len(v)) if v else (0.0, 0)
+
+    out = {"note": "rocprofv3 --pmc passes (separate runs, --kernel-trace only) of `python bench.py --no-cpu-baseline "
+                   f"--steps 5 --dtype {dt}` (B=4096, N=200). FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md "
+                   "(HBM section) FETCH_SIZE on gfx950 reports exactly half of a wide coalesced streaming read, so "
+                   "read bytes = 2 * FETCH_SIZE * 1024.",
+           "dtype": dt, "batch": 4096, "horizon": 200, "kernels": {}}
+    for kern in ("backward_tile16_kernel", "linearize_kernel", "forward_kernel"):
+        f, nf = mean_counter(fetch[0], kern)
+        w, nw = mean_counter(write[0], kern)
+        out["kernels"][kern] = {"FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "launches": nf,
+                                "read_bytes_corrected": 2 * f * 1024, "write_bytes": w * 1024,
+                                "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
+    json.dump(out, open(os.path.join(dst, f"pmc_traffic_{dt}.json"), "w"), indent=1)
+    print(dt, {k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out["kernels"].items()}, "MB per launch")
+for dt in ("f32", "f64"):
+    p = os.path.join(dst, f"rocprofv3_kernel_stats_{dt}.csv")
+    if os.path.exists(p):
+        print(dt, [(r["Name"][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in csv.DictReader(open(p))
+                   if float(r["Percentage"]) > 0.5])
