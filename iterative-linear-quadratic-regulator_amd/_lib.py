@@ -16,7 +16,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libilqr_hip.so"
-LIB_PATH = os.path.join(HERE, LIB_NAME)
+LIB_PATH = os.environ.get("ILQR_LIB") or os.path.join(HERE, LIB_NAME)   # ILQR_LIB: A/B builds (tools/)
 CSRC = os.path.join(HERE, "csrc")
 
 # ---- enums (include/ilqr_hip.h) --------------------------------------------------

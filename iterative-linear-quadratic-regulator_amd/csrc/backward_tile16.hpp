@@ -71,6 +71,8 @@ constexpr int kTile16 = 48;
 // ---- buffer addressing (SRSRC): address = base + voffset(lane, set once) + soffset(scalar, per step) +
 // immediate.  The sweep's per-step address arithmetic is then ONE scalar multiply instead of four 64-bit
 // vector adds per tile (cdna_hip_programming.md T8: it pays "as part of other addressing idioms").
+// cache policy of the tile stream (aux = 2: nt -- each tile byte is read exactly once per sweep)
+constexpr int kTileAux = ILQR_NT_TILE_LOAD ? 2 : 0;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 // Uniformity must be PROVABLE to hipcc or every buffer op is wrapped in a ~10-instruction waterfall loop
@@ -86,22 +88,22 @@ ILQR_DEV __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
 template <int IMM, typename T> struct BufLoad;
 template <int IMM> struct BufLoad<IMM, float> {
     static ILQR_DEV void v4(__amdgpu_buffer_rsrc_t r, int voff, int soff, float* o) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 4, soff, 0);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 4, soff, kTileAux);
         o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
     }
     static ILQR_DEV float v1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff + IMM * 4, soff, 0));
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff + IMM * 4, soff, kTileAux));
     }
 };
 template <int IMM> struct BufLoad<IMM, double> {
     static ILQR_DEV void v4(__amdgpu_buffer_rsrc_t r, int voff, int soff, double* o) {
-        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 8, soff, 0);
-        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 8 + 16, soff, 0);
+        const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 8, soff, kTileAux);
+        const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + IMM * 8 + 16, soff, kTileAux);
         o[0] = __hiloint2double((int)a.y, (int)a.x); o[1] = __hiloint2double((int)a.w, (int)a.z);
         o[2] = __hiloint2double((int)b.y, (int)b.x); o[3] = __hiloint2double((int)b.w, (int)b.z);
     }
     static ILQR_DEV double v1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM * 8, soff, 0);
+        const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, voff + IMM * 8, soff, kTileAux);
         return __hiloint2double((int)a.y, (int)a.x);
     }
 };
@@ -144,6 +146,78 @@ ILQR_DEV void tile16_load_buf(Tile16<T>& tl, __amdgpu_buffer_rsrc_t r, const Til
     tl.lxx = BufLoad<16, T>::v1(r, o.vl, soff);    // l_xx[i][j]
     tl.bi = BufLoad<32, T>::v1(r, o.vi, soff);     // f_u[i]
 }
+
+// ---- tile loads hipcc does not count -------------------------------------------------------------------
+// hipcc places its own s_waitcnt for loads it can see, and at a loop edge it drains them all (measured:
+// vmcnt(0..5) at the top of every ring pass = one exposed memory latency per D steps; with the tiles coming
+// from HBM rather than from the Infinity Cache that is ~2 us per pass).  The ring's loads are therefore
+// issued from inline asm, which hipcc's bookkeeping does not see, and the kernel counts vmcnt itself
+// (cdna_hip_programming.md 5.7, form (ii): "=v" loads, then before the first consumer a wait statement
+// naming every destination "+v").  Loads, stores and LDS-DMA retire in issue order; one step issues
+// NLOAD tile loads and exactly one gain store, so "slot u has landed" == at most (D-1)*(NLOAD+1) younger
+// operations outstanding in steady state, (D-1)*NLOAD while the prologue's loads are still the only ones.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef double f64x2n __attribute__((ext_vector_type(2)));
+
+ILQR_DEV i32x4 make_srd(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 d;
+    d.x = uniform((int)(unsigned)a);
+    d.y = uniform((int)((unsigned)(a >> 32) & 0xffffu));   // stride 0
+    d.z = uniform((int)bytes);
+    d.w = 0x00020000;
+    return d;
+}
+
+template <typename T> struct RawTile;
+template <> struct RawTile<float> {
+    static constexpr int NLOAD = 5;
+    f32x4n ski, skj, vj;
+    float lxx, bi;
+    ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ski) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(skj) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(vj) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:64" : "=v"(lxx) : "v"(o.vl), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:128" : "=v"(bi) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+    }
+    template <int N> ILQR_DEV void wait() {
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ski), "+v"(skj), "+v"(vj), "+v"(lxx), "+v"(bi) : "i"(N) : "memory");
+    }
+    ILQR_DEV void unpack(Tile16<float>& t) const {
+        t.ski[0] = ski.x; t.ski[1] = ski.y; t.ski[2] = ski.z; t.ski[3] = ski.w;
+        t.skj[0] = skj.x; t.skj[1] = skj.y; t.skj[2] = skj.z; t.skj[3] = skj.w;
+        t.vj[0] = vj.x; t.vj[1] = vj.y; t.vj[2] = vj.z; t.vj[3] = vj.w;
+        t.lxx = lxx; t.bi = bi;
+    }
+};
+template <> struct RawTile<double> {
+    static constexpr int NLOAD = 8;
+    f64x2n ski0, ski1, skj0, skj1, vj0, vj1;
+    double lxx, bi;
+    ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ski0) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(ski1) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(skj0) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(skj1) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:256" : "=v"(vj0) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:272" : "=v"(vj1) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:128" : "=v"(lxx) : "v"(o.vl), "s"(srd), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:256" : "=v"(bi) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+    }
+    template <int N> ILQR_DEV void wait() {
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(ski0), "+v"(ski1), "+v"(skj0), "+v"(skj1), "+v"(vj0), "+v"(vj1), "+v"(lxx), "+v"(bi)
+                     : "i"(N) : "memory");
+    }
+    ILQR_DEV void unpack(Tile16<double>& t) const {
+        t.ski[0] = ski0.x; t.ski[1] = ski0.y; t.ski[2] = ski1.x; t.ski[3] = ski1.y;
+        t.skj[0] = skj0.x; t.skj[1] = skj0.y; t.skj[2] = skj1.x; t.skj[3] = skj1.y;
+        t.vj[0] = vj0.x; t.vj[1] = vj0.y; t.vj[2] = vj1.x; t.vj[3] = vj1.y;
+        t.lxx = lxx; t.bi = bi;
+    }
+};
 
 // acc += coef * (w moved across lanes by a DPP pattern), as ONE instruction (v_fmac_f32_dpp).  hipcc's
 // DPP combiner folds a lane move into v_mul / v_add but not into the accumulating v_fmac (tied operand), so
@@ -338,7 +412,8 @@ constexpr int kTile16PinLds = 84 * 1024;
 
 template <typename T, bool REG>
 __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
-    constexpr int D = sizeof(T) == 4 ? 8 : 5;  // tiles in flight per lane (vmcnt holds 63 operations)
+    // tiles in flight per lane: (D-1) * (loads per tile + 1 store) must stay <= 63 (the vmcnt field)
+    constexpr int D = sizeof(T) == 4 ? 10 : 7;
     constexpr int R = gain_record(4, 1);       // 8
     const int lane = threadIdx.x & 63;
     const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
@@ -391,21 +466,37 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
         do_step(c, t);
     }
     if (t >= 0) {
-        Tile16<T> ring[D];
+        // D tiles per lane in flight, loaded by asm and waited for with self-counted vmcnt (see RawTile)
+        constexpr int NL = RawTile<T>::NLOAD;
+        const i32x4 srd = make_srd(a.lin, lin_bytes);
+        RawTile<T> ring[D];
 #pragma unroll
-        for (int u = 0; u < D; ++u) tile16_load_buf(ring[u], rlin, off, uniform((t - u) * tstride));
-        for (; t >= 0; t -= D) {
+        for (int u = 0; u < D; ++u) ring[u].issue(srd, off, uniform((t - u) * tstride));
+        // first ring pass: only the prologue's loads (plus this pass's own stores / refills) are in flight
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            ring[u].template wait<(D - 1) * NL>();
+            Tile16<T> c;
+            ring[u].unpack(c);
+            do_step(c, t - u);
+            const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
+            ring[u].issue(srd, off, uniform(tn * tstride));
+        }
+        for (t -= D; t >= 0; t -= D) {
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                // consume ring slot u, then refill the SAME registers with the tile D steps ahead (their
-                // old contents are dead by then, so no copies and no full drain at the loop edge).  The
-                // refill is unconditional (clamped to tile 0 at the end of the sweep): the body stays
-                // branch-free and D-1 tiles per lane stay in flight.
-                do_step(ring[u], t - u);
+                // slot u was refilled D steps ago; since then (D-1) steps issued 1 store + NL loads each
+                ring[u].template wait<(D - 1) * (NL + 1)>();
+                Tile16<T> c;
+                ring[u].unpack(c);
+                do_step(c, t - u);
+                // refill the SAME registers with the tile D steps ahead (clamped to tile 0 at the end of the
+                // sweep: the body stays branch-free; the surplus loads are drained before the kernel ends)
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
-                tile16_load_buf(ring[u], rlin, off, uniform(tn * tstride));
+                ring[u].issue(srd, off, uniform(tn * tstride));
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     cp.stop(a.probe, 0);
     if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;

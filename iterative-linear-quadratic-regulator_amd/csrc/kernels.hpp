@@ -19,6 +19,13 @@
 
 namespace ilqr {
 
+// cache-policy switches (compile-time; A/B'd with tools/build_variants.sh, results in DESIGN.md)
+#ifndef ILQR_NT_TILE_STORE
+#define ILQR_NT_TILE_STORE 0
+#endif
+#ifndef ILQR_NT_TILE_LOAD
+#define ILQR_NT_TILE_LOAD 0
+#endif
 constexpr int kMaxAlpha = 16;
 constexpr int kCounterRing = 64;
 
@@ -139,23 +146,37 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
             tile[8 + j].x = fu[j][0]; tile[8 + j].y = gx[j]; tile[8 + j].z = T(0);
             tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? p[PL::RS] * a.dt : T(0));
         }
-        constexpr int CH = sizeof(T) == 4 ? 12 : 6;   // V4s per lane per chunk (keeps LDS at ~14 KB per wave)
-        constexpr int ROW = CH + 1;                   // padded row: conflict-free 16-B-per-lane writes
-        __shared__ V4 xpose[64 * ROW];
+        // passes over groups of whole tiles (so every pass writes one contiguous run of full cache lines):
+        // 64 tiles at once in f32, 2 x 32 tiles in f64; ~13 KB of LDS per wave either way
+        constexpr int PASSES = sizeof(T) / 4, TPP = 64 / PASSES, ROW = 13;   // 12 V4 per tile + 1 pad
+        __shared__ V4 xpose[TPP * ROW];
         const int lane = threadIdx.x;
         const unsigned long long okmask = __ballot(point);
         V4* gout = reinterpret_cast<V4*>(a.lin) + (size_t)blockIdx.x * 64 * 12;   // first tile of this wave
 #pragma unroll
-        for (int c = 0; c < 12 / CH; ++c) {
-            if (c) __syncthreads();
+        for (int ps = 0; ps < PASSES; ++ps) {
+            if (ps) __syncthreads();
+            if (lane / TPP == ps) {
 #pragma unroll
-            for (int q = 0; q < CH; ++q) xpose[lane * ROW + q] = tile[c * CH + q];
+                for (int q = 0; q < 12; ++q) xpose[(lane % TPP) * ROW + q] = tile[q];
+            }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < CH; ++r) {
-                const int v = lane + 64 * r;          // v-th V4 of this chunk, tile-major
-                const int k = v / CH, q = v % CH;
-                if ((okmask >> k) & 1ull) gout[(size_t)k * 12 + c * CH + q] = xpose[k * ROW + q];
+            for (int r = 0; r < 12 / PASSES; ++r) {
+                const int v = lane + 64 * r;          // v-th V4 of this pass, tile-major
+                const int kl = v / 12, q = v % 12, k = ps * TPP + kl;
+                if ((okmask >> k) & 1ull) {
+                    // streamed once to the backward sweep (usually on another XCD)
+                    const V4 val = xpose[kl * ROW + q];
+                    V4* dst = &gout[(size_t)k * 12 + q];
+                    typedef T nv4 __attribute__((ext_vector_type(4)));
+                    if (ILQR_NT_TILE_STORE) {
+                        const nv4 nv = {val.x, val.y, val.z, val.w};
+                        __builtin_nontemporal_store(nv, reinterpret_cast<nv4*>(dst));
+                    } else {
+                        *dst = val;
+                    }
+                }
             }
         }
         return;
