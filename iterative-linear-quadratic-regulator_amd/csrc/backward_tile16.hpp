@@ -156,6 +156,11 @@ ILQR_DEV void tile16_load_buf(Tile16<T>& tl, __amdgpu_buffer_rsrc_t r, const Til
 // naming every destination "+v").  Loads, stores and LDS-DMA retire in issue order; one step issues
 // NLOAD tile loads and exactly one gain store, so "slot u has landed" == at most (D-1)*(NLOAD+1) younger
 // operations outstanding in steady state, (D-1)*NLOAD while the prologue's loads are still the only ones.
+#if ILQR_NT_TILE_LOAD
+#define ILQR_TILE_NT " nt"
+#else
+#define ILQR_TILE_NT ""
+#endif
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4n __attribute__((ext_vector_type(4)));
 typedef double f64x2n __attribute__((ext_vector_type(2)));
@@ -171,16 +176,27 @@ ILQR_DEV i32x4 make_srd(const void* base, unsigned bytes) {
 }
 
 template <typename T> struct RawTile;
+// All loads of a tile are ONE asm statement opening with s_nop 4: every SGPR operand (descriptor, soffset) is
+// then materialised before the statement, and a value hipcc produced with a VALU (v_readfirstlane, or a
+// v_readlane restoring a spilled SGPR) has its 5 wait states before a buffer instruction reads it -- hipcc
+// cannot pad hazards inside an asm string (cdna_hip_programming.md 5.7 item 2).  Without this the f64 rollout,
+// which runs out of SGPRs, read a half-restored descriptor and faulted.  Outputs are early-clobber: a later
+// load of the statement must not see its address register overwritten by an earlier one.
 template <> struct RawTile<float> {
     static constexpr int NLOAD = 5;
     f32x4n ski, skj, vj;
     float lxx, bi;
     ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ski) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(skj) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:128" : "=v"(vj) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:64" : "=v"(lxx) : "v"(o.vl), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:128" : "=v"(bi) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %5, %8, %9 offen" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %1, %6, %8, %9 offen" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %2, %6, %8, %9 offen offset:128" ILQR_TILE_NT "\n\t"
+            "buffer_load_dword %3, %7, %8, %9 offen offset:64" ILQR_TILE_NT "\n\t"
+            "buffer_load_dword %4, %5, %8, %9 offen offset:128" ILQR_TILE_NT
+            : "=&v"(ski), "=&v"(skj), "=&v"(vj), "=&v"(lxx), "=&v"(bi)
+            : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)
+            : "memory");
     }
     template <int N> ILQR_DEV void wait() {
         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ski), "+v"(skj), "+v"(vj), "+v"(lxx), "+v"(bi) : "i"(N) : "memory");
@@ -197,14 +213,19 @@ template <> struct RawTile<double> {
     f64x2n ski0, ski1, skj0, skj1, vj0, vj1;
     double lxx, bi;
     ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(ski0) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(ski1) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(skj0) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:16" : "=v"(skj1) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:256" : "=v"(vj0) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:272" : "=v"(vj1) : "v"(o.vj), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:128" : "=v"(lxx) : "v"(o.vl), "s"(srd), "s"(soff) : "memory");
-        asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen offset:256" : "=v"(bi) : "v"(o.vi), "s"(srd), "s"(soff) : "memory");
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %8, %11, %12 offen" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %1, %8, %11, %12 offen offset:16" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %2, %9, %11, %12 offen" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %3, %9, %11, %12 offen offset:16" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %4, %9, %11, %12 offen offset:256" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %5, %9, %11, %12 offen offset:272" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx2 %6, %10, %11, %12 offen offset:128" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx2 %7, %8, %11, %12 offen offset:256" ILQR_TILE_NT
+            : "=&v"(ski0), "=&v"(ski1), "=&v"(skj0), "=&v"(skj1), "=&v"(vj0), "=&v"(vj1), "=&v"(lxx), "=&v"(bi)
+            : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)
+            : "memory");
     }
     template <int N> ILQR_DEV void wait() {
         asm volatile("s_waitcnt vmcnt(%8)"
@@ -491,7 +512,11 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
                 ring[u].unpack(c);
                 do_step(c, t - u);
                 // refill the SAME registers with the tile D steps ahead (clamped to tile 0 at the end of the
-                // sweep: the body stays branch-free; the surplus loads are drained before the kernel ends)
+                // sweep: the body stays branch-free; the surplus loads are drained before the kernel ends).
+                // (Issuing the refill in the middle of the NEXT step instead, inside its latency-bound tail,
+                // was tried: 43.8 vs 40.6 us -- the extra asm statement splits hipcc's schedule of the tail.).
+                // (Issuing the refill in the middle of the NEXT step instead, inside its latency-bound tail,
+                // was tried: 43.8 vs 40.6 us -- the extra asm statement splits hipcc's schedule of the tail.)
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
                 ring[u].issue(srd, off, uniform(tn * tstride));
             }

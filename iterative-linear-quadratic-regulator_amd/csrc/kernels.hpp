@@ -21,7 +21,7 @@ namespace ilqr {
 
 // cache-policy switches (compile-time; A/B'd with tools/build_variants.sh, results in DESIGN.md)
 #ifndef ILQR_NT_TILE_STORE
-#define ILQR_NT_TILE_STORE 0
+#define ILQR_NT_TILE_STORE 1   // measured: forward 216 -> 191 us (f32), 359 -> 340 us (f64), sweep unchanged
 #endif
 #ifndef ILQR_NT_TILE_LOAD
 #define ILQR_NT_TILE_LOAD 0
@@ -161,21 +161,23 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
                 for (int q = 0; q < 12; ++q) xpose[(lane % TPP) * ROW + q] = tile[q];
             }
             __syncthreads();
+            // read back in 16-byte units, tile-major: one wave-instruction = 64 lanes x 16 B = 1 KiB of
+            // consecutive addresses, whatever the scalar type (a 32-B f64 V4 split over two instructions
+            // would leave every instruction writing half lines, which non-temporal stores punish)
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            constexpr int UPT = 12 * (int)sizeof(T) / 4;           // 16-B units per tile: 12 / 24
+            constexpr int UPV = (int)sizeof(T) / 4;                // units per V4: 1 / 2
+            const u4* xs = reinterpret_cast<const u4*>(xpose);
+            u4* gu = reinterpret_cast<u4*>(gout);
 #pragma unroll
-            for (int r = 0; r < 12 / PASSES; ++r) {
-                const int v = lane + 64 * r;          // v-th V4 of this pass, tile-major
-                const int kl = v / 12, q = v % 12, k = ps * TPP + kl;
+            for (int r = 0; r < 12; ++r) {
+                const int w = lane + 64 * r;          // w-th unit of this pass
+                const int kl = w / UPT, q = w % UPT, k = ps * TPP + kl;
                 if ((okmask >> k) & 1ull) {
-                    // streamed once to the backward sweep (usually on another XCD)
-                    const V4 val = xpose[kl * ROW + q];
-                    V4* dst = &gout[(size_t)k * 12 + q];
-                    typedef T nv4 __attribute__((ext_vector_type(4)));
-                    if (ILQR_NT_TILE_STORE) {
-                        const nv4 nv = {val.x, val.y, val.z, val.w};
-                        __builtin_nontemporal_store(nv, reinterpret_cast<nv4*>(dst));
-                    } else {
-                        *dst = val;
-                    }
+                    const u4 val = xs[kl * ROW * UPV + q];
+                    u4* dst = &gu[(size_t)k * UPT + q];
+                    if (ILQR_NT_TILE_STORE) __builtin_nontemporal_store(val, dst);
+                    else *dst = val;
                 }
             }
         }
@@ -558,6 +560,116 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
     cost += Cost<T, Dyn>::terminal(p, x);
     a.costs[(size_t)ai * B + b] = cost;
+    cp.stop(a.probe, 1);
+}
+
+// ---------------------------------------------------------------------------
+// forward rollout, ring form (small systems, tensors < 2 GiB): identical arithmetic to forward_kernel, but
+// the per-step inputs (x_old, u_old, gain record) are kept PF steps ahead in registers by inline-asm buffer
+// loads with self-counted vmcnt (same technique and same reasons as RawTile in backward_tile16.hpp: hipcc
+// drains every load it can see at the loop edge, and one RK4 step is shorter than an HBM round trip under
+// load).  Per step the wave issues NLD asm loads and NX + NU compiler stores (the candidate trajectory), all
+// retiring in issue order, so "slot q has landed" == at most (PF-1) * (NLD + NX + NU) younger operations.
+// ---------------------------------------------------------------------------
+#include "fwd_in_gen.inc"
+
+template <typename T, typename Dyn, int INTEG>
+__global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    using In = FwdIn<T, NX, NU>;
+    constexpr int R = In::R, NLD = In::NLD, NST = NX + NU;
+    constexpr int PF = (63 / (NLD + NST)) + 1 > 6 ? 6 : (63 / (NLD + NST)) + 1;   // (PF-1)*(NLD+NST) <= 63
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ai = blockIdx.y;
+    const bool live = b < a.B && traj_active(a.status[b < a.B ? b : 0]) && !a.accepted[b < a.B ? b : 0];
+    if (__ballot(live) == 0ull) return;
+    const int bb = live ? b : 0;          // dead lanes shadow trajectory 0 and never store
+    const size_t B = a.B;
+    const int N = a.N;
+    const int slot = a.cur_slot[bb];
+    const int cslot = (slot + 1 + ai) % a.n_slots;
+    const T alpha = a.alphas[ai];
+    // The parameter block is copied into registers once: the asm statements below carry "memory" clobbers
+    // (they pin the order of loads and stores the vmcnt arithmetic relies on), and a clobber would otherwise
+    // make hipcc reload every parameter from memory after each of them.
+    using PLp = ParamLayout<Dyn::NSYS, NX, NU>;
+    T p[PLp::QS];   // [system constants | x_target | Q | R | Q_f]: all the rollout reads
+#pragma unroll
+    for (int i = 0; i < PLp::QS; ++i) p[i] = a.params[i];
+    T x[NX], u[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = a.x0[(size_t)i * B + bb];
+    ClockProbe cp;
+    cp.start();
+    T cost = T(0);
+    T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + bb;
+    T* Uc = a.U + ((size_t)cslot * N * NU) * B + bb;
+    const int rowB = (int)(B * sizeof(T));
+    const i32x4 srdX = make_srd(a.X, (unsigned)((size_t)a.n_slots * (N + 1) * NX * B * sizeof(T)));
+    const i32x4 srdU = make_srd(a.U, (unsigned)((size_t)a.n_slots * N * NU * B * sizeof(T)));
+    const i32x4 srdG = make_srd(a.gains, (unsigned)((size_t)N * B * R * sizeof(T)));
+    const int vx = (int)(((size_t)slot * (N + 1) * NX * B + bb) * sizeof(T));
+    const int vu = (int)(((size_t)slot * N * NU * B + bb) * sizeof(T));
+    const int vg = (int)((size_t)bb * R * sizeof(T));
+    auto issue = [&](In& in, int t) { in.issue(srdX, srdU, srdG, vx, vu, vg, t * NX * rowB, t * NU * rowB, t * R * rowB, rowB); };
+    auto do_step = [&](const In& in, int t) {
+        T dx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - in.xo[i];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            T fb = T(0);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) fb += in.gain(j * NX + i) * dx[i];
+            u[j] = in.uo[j] + alpha * in.gain(NU * NX + j) + fb;   // iLQR_class.py:181-182
+        }
+        // exactly NX + NU stores per step for every wave that is still running (they are counted)
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+            if (live) Xc[((size_t)t * NX + i) * B] = x[i];
+#pragma unroll
+        for (int j = 0; j < NU; ++j)
+            if (live) Uc[((size_t)t * NU + j) * B] = u[j];
+        cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
+        T xn[NX];
+        Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = xn[i];
+    };
+    int t = 0;
+    // leading remainder: one slot, fully waited (whole rings only in the pipelined loop)
+    for (int r = N % PF; r > 0; --r, ++t) {
+        In in;
+        issue(in, t);
+        in.template wait<0>();
+        do_step(in, t);
+    }
+    if (t < N) {
+        In ring[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) issue(ring[q], t + q);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {   // first pass: the prologue loads may be the only operations in flight
+            ring[q].template wait<(PF - 1) * NLD>();
+            do_step(ring[q], t + q);
+            issue(ring[q], (t + q + PF < N) ? t + q + PF : N - 1);
+        }
+        for (t += PF; t < N; t += PF) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                ring[q].template wait<(PF - 1) * (NLD + NST)>();
+                do_step(ring[q], t + q);
+                issue(ring[q], (t + q + PF < N) ? t + q + PF : N - 1);   // clamped: branch-free refill
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (live) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
+        cost += Cost<T, Dyn>::terminal(p, x);
+        a.costs[(size_t)ai * B + b] = cost;
+    }
     cp.stop(a.probe, 1);
 }
 

@@ -106,7 +106,17 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
         ILQR_LAUNCH((linearize_kernel<T, Dyn, TILE, I>), dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, s, a);
     };
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
-        ILQR_LAUNCH((forward_kernel<T, Dyn, I>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+        const dim3 grid((a.B + 63) / 64, a.n_pass), block(64);
+        if constexpr (SMALL) {
+            // ring form: 32-bit buffer offsets into X (the largest tensor), and a switch for A/B runs
+            static const bool plain = getenv("ILQR_FORWARD_PLAIN") != nullptr;
+            const bool fits = (size_t)a.n_slots * (a.N + 1) * Dyn::NX * a.B * sizeof(T) < (1ull << 31);
+            if (fits && !plain) {
+                ILQR_LAUNCH((forward_ring_kernel<T, Dyn, I>), grid, block, 0, s, a);
+                return;
+            }
+        }
+        ILQR_LAUNCH((forward_kernel<T, Dyn, I>), grid, block, 0, s, a);
     };
 }
 

@@ -65,6 +65,66 @@ def local_stats(cost, cost_prev, status):
                         dtype=torch.float64)
 
 
+class StatusExchange:
+    """The per-iteration inter-GPU exchange, off the critical path: each rank's 4-vector
+    {min cost, max |dcost|, #active, #converged} is all-gathered (ONE collective of 32 B per rank) on a side
+    stream while the compute stream goes straight on to the next iteration; the host reduces the gathered
+    rows when it wants the global status.  Double-buffered, so a launch never overwrites the operand of a
+    collective that may still be reading it.  Works on CUDA tensors (nccl = RCCL over xGMI) and on CPU
+    tensors (gloo, used by the tests; no streams there)."""
+
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = device is not None and str(device) != "cpu"
+        dev = device if self.cuda else "cpu"
+        self.stats = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.gathered = [torch.zeros(self.world, 4, dtype=torch.float64, device=dev) for _ in range(2)]
+        self.k = 0
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=dev)
+            self.done = [None, None]
+
+    def launch(self, fill):
+        """fill(stats_tensor) writes this rank's 4-vector on the CURRENT stream (e.g. handle.status_reduce)."""
+        torch, dist = self.torch, self.dist
+        i = self.k & 1
+        self.k += 1
+        if self.cuda:
+            cur = torch.cuda.current_stream()
+            if self.done[i] is not None:
+                cur.wait_event(self.done[i])      # the collective that last used this buffer pair has finished
+            fill(self.stats[i])
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                self._gather(i)
+                self.done[i] = torch.cuda.Event()
+                self.done[i].record(self.side)
+        else:
+            fill(self.stats[i])
+            self._gather(i)
+        return i
+
+    def _gather(self, i):
+        if self.world == 1:
+            self.gathered[i][0].copy_(self.stats[i])
+        else:
+            self.dist.all_gather(list(self.gathered[i].unbind(0)), self.stats[i], group=self.group)
+
+    def result(self, i=None) -> GlobalStatus:
+        if i is None:
+            i = (self.k - 1) & 1
+        if self.cuda:
+            self.side.synchronize()
+        g = self.gathered[i].cpu()
+        return GlobalStatus(min_cost=float(g[:, 0].min()), max_dcost=float(g[:, 1].max()),
+                            n_active=int(round(float(g[:, 2].sum()))), n_converged=int(round(float(g[:, 3].sum()))))
+
+
 class ShardedBatch:
     """Splits a global batch (x0 (B, n), U_init (B, m, N)) over the ranks of the default process group
     and solves the local shard with ``iLQR``; ``global_status()`` is the RCCL all-reduce."""

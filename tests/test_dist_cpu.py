@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ilqr_amd.dist import shard_range, allreduce_status, local_stats, to_status
+from ilqr_amd.dist import shard_range, allreduce_status, local_stats, to_status, StatusExchange
 
 
 def test_shard_ranges_partition_the_batch():
@@ -39,8 +39,13 @@ def _worker(rank, world, port, q):
     status = rng.integers(0, 4, total)
     lo, hi = shard_range(total, world, rank)
     s = local_stats(cost[lo:hi], prev[lo:hi], status[lo:hi])
+    x = StatusExchange()                 # the all-gather form used by bench.py (CPU tensors here)
+    for _ in range(3):                   # several launches: exercises the double buffering
+        x.launch(lambda t: t.copy_(s))
+    gx = x.result()
     allreduce_status(s)
     g = to_status(s)
+    assert (gx.min_cost, gx.max_dcost, gx.n_active, gx.n_converged) == (g.min_cost, g.max_dcost, g.n_active, g.n_converged)
     q.put((rank, g.min_cost, g.max_dcost, g.n_active, g.n_converged,
            float(cost.min()), float(np.abs(cost - prev).max()), int((status == 0).sum()), int((status == 1).sum())))
     dist.barrier()

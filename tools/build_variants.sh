@@ -13,8 +13,8 @@ build s0l0c0
 build s1l0c0 -DILQR_NT_TILE_STORE=1
 build s0l1c0 -DILQR_NT_TILE_LOAD=1
 build s1l1c0 -DILQR_NT_TILE_STORE=1 -DILQR_NT_TILE_LOAD=1
-build s0l0c1 -DILQR_NT_CAND_STORE=1
-build s0l1c1 -DILQR_NT_TILE_LOAD=1 -DILQR_NT_CAND_STORE=1
-build s1l0c1 -DILQR_NT_TILE_STORE=1 -DILQR_NT_CAND_STORE=1
-build s1l1c1 -DILQR_NT_TILE_STORE=1 -DILQR_NT_TILE_LOAD=1 -DILQR_NT_CAND_STORE=1
+
+
+
+
 ls -la ../../tools/variants
