@@ -3,6 +3,12 @@ profiles/rNN (tracked): bench JSON lines, rocprofv3 --kernel-trace --stats summa
 traffic of the hot kernels (FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md)."""
 import csv, glob, json, os, shutil, sys
 
+
+def newest(pattern):
+    """gpurun merges every run's files into gpurun_out/: take the most recent match."""
+    m = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return m[-1:] 
+
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src, dst = "gpurun_out/prof", os.path.join("profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -10,10 +16,10 @@ for name, out in (("bench_default.json", "bench_default_f32.json"), ("bench_f64.
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out))
 for dt in ("f32", "f64"):
-    for f in glob.glob(f"{src}/trace_{dt}/*/*_kernel_stats.csv"):
+    for f in newest(f"{src}/trace_{dt}/*/*_kernel_stats.csv"):
         shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_{dt}.csv"))
-    fetch = glob.glob(f"{src}/pmc_fetch_{dt}/*/*_counter_collection.csv")
-    write = glob.glob(f"{src}/pmc_write_{dt}/*/*_counter_collection.csv")
+    fetch = newest(f"{src}/pmc_fetch_{dt}/*/*_counter_collection.csv")
+    write = newest(f"{src}/pmc_write_{dt}/*/*_counter_collection.csv")
     if not (fetch and write):
         continue
     shutil.copy(fetch[0], os.path.join(dst, f"rocprofv3_pmc_FETCH_SIZE_{dt}.csv"))
@@ -28,7 +34,7 @@ for dt in ("f32", "f64"):
                    "(HBM section) FETCH_SIZE on gfx950 reports exactly half of a wide coalesced streaming read, so "
                    "read bytes = 2 * FETCH_SIZE * 1024.",
            "dtype": dt, "batch": 4096, "horizon": 200, "kernels": {}}
-    for kern in ("backward_tile16_kernel", "linearize_kernel", "forward_kernel"):
+    for kern in ("backward_tile16_kernel", "linearize_kernel", "forward_ring_kernel"):
         f, nf = mean_counter(fetch[0], kern)
         w, nw = mean_counter(write[0], kern)
         out["kernels"][kern] = {"FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "launches": nf,
