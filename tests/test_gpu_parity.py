@@ -372,3 +372,30 @@ def test_full_size_properties_c3():
         uff_o, K_o = co.backward_pass(X[b], U[b])
         np.testing.assert_allclose(K_a[b], K_o, rtol=RTOL, atol=1e-9)
         np.testing.assert_allclose(uff_a[b], uff_o, rtol=RTOL, atol=1e-9)
+
+
+def test_c4_mpc_instances_at_shard_size():
+    """BASELINE config c4 at one GPU's shard: 1024 warm-started MPC instances of the under-actuated double
+    pendulum (run_iLQR_UA_MPC.py:17-174: rk4 optimiser, backward_euler plant, maxiter 50 -> 6 here), a few
+    receding-horizon steps on the device; sampled instances against the C oracle's closed loop."""
+    from oracle.c_oracle import COracle
+    p = problems.ua_double_pendulum(N=60)
+    B, n_sim, maxiter = 1024, 3, 6
+    x0, U0 = problems.ua_batch(B, seed=2, restarts=False, N=60)
+    st = ilqr_amd.mpc_init(p["dynamics"], p["cost"], x0, U0, plant_integrator="backward_euler", N=60, tol=p["tol"],
+                           maxiter=maxiter)
+    U_sim, X_sim, costs = st.solver.mpc_run(n_sim)
+    assert U_sim.shape == (n_sim, B, 1) and X_sim.shape == (n_sim, B, 4) and np.isfinite(costs).all()
+    co = COracle(p["dynamics"], p["cost"])
+    plant = COracle(p["dynamics"], p["cost"], integrator="backward_euler")
+    for b in (0, 517, 1023):
+        x, U_guess, state = x0[b].copy(), U0[b].copy(), None
+        for k in range(n_sim):
+            r = co.solve(x, U_guess, tol=p["tol"], maxiter=maxiter, state=state)
+            u0 = r["U"][:, 0]
+            x = plant.step(x, u0, jac=False)[0]
+            np.testing.assert_allclose(U_sim[k, b], u0, rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(X_sim[k, b], x, rtol=1e-5, atol=1e-8)
+            np.testing.assert_allclose(costs[k, b], r["cost"], rtol=RTOL)
+            U_guess = np.concatenate([r["U"][:, 1:], r["U"][:, -1:]], axis=1)
+            state = (r["X"], r["U_ff"], r["K"])
