@@ -84,8 +84,147 @@ __global__ void __launch_bounds__(64) linearize_wave_kernel(KArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------
+// forward rollout for linear systems, n_x > 4: ONE WAVE per (trajectory, alpha) candidate.
+// The system is time-invariant, so every lane keeps its share of A (or I + dt A), B (or dt B), Q, R, Q_f
+// in registers for the whole rollout -- the lane-per-rollout kernel re-read the 704-entry parameter block
+// at every step (11.8 us/step at n = 16).  Lane (i, p) = (row i of A, part p of its columns); the state and
+// the control of the current step live in LDS and every lane reads the pieces it needs; dot products are
+// finished by xor-shuffles over the lanes of a row.  Replaces iLQR._forward_pass_scan
+// (iLQR_class.py:193-247) exactly like forward_kernel.
+// ---------------------------------------------------------------------------
+template <typename T> ILQR_DEV T shfl_xor_t(T v, int mask) { return __shfl_xor(v, mask, 64); }
+
+template <typename T, int NX, int NU>
+__global__ void __launch_bounds__(64) forward_wave_kernel(KArgs<T> a) {
+    using Dyn = Linear<T, NX, NU>;
+    using PL = ParamLayout<Dyn::NSYS, NX, NU>;
+    constexpr int R = gain_record(NX, NU);
+    constexpr int PR = 64 / NX;                 // lanes per row of A
+    constexpr int CA = NX / PR;                 // A / Q columns per lane
+    constexpr int CB = (NU + PR - 1) / PR;      // B columns per lane (masked beyond NU)
+    constexpr int PK = 64 / NU;                 // lanes per row of K
+    constexpr int CK = (NX + PK - 1) / PK;      // K columns per lane (masked beyond NX)
+    static_assert(64 % NX == 0 && 64 % NU == 0 && NX % PR == 0, "lane mapping needs NX, NU dividing 64");
+    const int b = blockIdx.x, ai = blockIdx.y;
+    const int lane = threadIdx.x;
+    if (!traj_active(a.status[b]) || a.accepted[b]) return;
+    const size_t B = a.B;
+    const int N = a.N;
+    const int slot = a.cur_slot[b];
+    const int cslot = (slot + 1 + ai) % a.n_slots;
+    const T alpha = a.alphas[ai];
+    const T* __restrict__ p = a.params;
+    const bool discrete = a.integ == ILQR_INT_DISCRETE;
+    const int i = lane / PR, pa = lane % PR;    // A mapping
+    const int j = lane / PK, pk = lane % PK;    // K mapping
+    T Aco[CA], Qco[CA], Qfco[CA], xtq[CA], Bco[CB];
+#pragma unroll
+    for (int q = 0; q < CA; ++q) {
+        const int c = pa * CA + q;
+        const T av = p[i * NX + c];
+        Aco[q] = discrete ? av : T(i == c) + a.dt * av;
+        Qco[q] = p[PL::Q + i * NX + c];
+        Qfco[q] = p[PL::QF + i * NX + c];
+        xtq[q] = p[PL::XT + c];
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+        const int c = pa * CB + q;
+        const T bv = c < NU ? p[NX * NX + i * NU + c] : T(0);
+        Bco[q] = discrete ? bv : a.dt * bv;
+    }
+    const T xti = p[PL::XT + i];
+    const int jr = lane / NU, cr = lane % NU;   // R mapping (lanes < NU*NU)
+    const T Rco = lane < NU * NU ? p[PL::R + jr * NU + cr] : T(0);
+
+    __shared__ T sx[NX], su[NU];
+    if (lane < NX) sx[lane] = a.x0[(size_t)lane * B + b];
+    __syncthreads();
+    const T* Xo = a.X + ((size_t)slot * (N + 1) * NX) * B + b;
+    const T* Uo = a.U + ((size_t)slot * N * NU) * B + b;
+    const T* G = a.gains + (size_t)b * R;
+    T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + b;
+    T* Uc = a.U + ((size_t)cslot * N * NU) * B + b;
+    T cx = T(0), cu = T(0);
+    for (int t = 0; t < N; ++t) {
+        // ---- u = u_old + alpha k + K (x - x_old)   (iLQR_class.py:181-182) -------------------------
+        T part = T(0);
+#pragma unroll
+        for (int e = 0; e < CK; ++e) {
+            const int c = pk * CK + e;
+            if (c < NX) part += G[(size_t)t * B * R + j * NX + c] * (sx[c] - Xo[((size_t)t * NX + c) * B]);
+        }
+#pragma unroll
+        for (int m = 1; m < PK; m <<= 1) part += shfl_xor_t(part, m);
+        const T uj = Uo[((size_t)t * NU + j) * B] + alpha * G[(size_t)t * B * R + NU * NX + j] + part;
+        if (pk == 0) {
+            su[j] = uj;
+            Uc[((size_t)t * NU + j) * B] = uj;
+        }
+        __syncthreads();
+        // ---- x+ = A x + B u ; stage cost partials ----------------------------------------------------
+        T acc = T(0), qpart = T(0);
+#pragma unroll
+        for (int q = 0; q < CA; ++q) {
+            const T xv = sx[pa * CA + q];
+            acc += Aco[q] * xv;
+            qpart += Qco[q] * (xv - xtq[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+            const int c = pa * CB + q;
+            if (c < NU) acc += Bco[q] * su[c];
+        }
+        const T xi = sx[i];
+        cx += (xi - xti) * qpart;
+        if (lane < NU * NU) cu += Rco * su[jr] * su[cr];
+#pragma unroll
+        for (int m = 1; m < PR; m <<= 1) acc += shfl_xor_t(acc, m);
+        if (pa == 0) Xc[((size_t)t * NX + i) * B] = xi;   // the state USED at this step (:188)
+        __syncthreads();
+        if (pa == 0) sx[i] = acc;
+        __syncthreads();
+    }
+    // terminal state and cost l_f = 0.5 dx' Q_f dx
+    T qf = T(0);
+#pragma unroll
+    for (int q = 0; q < CA; ++q) qf += Qfco[q] * (sx[pa * CA + q] - xtq[q]);
+    const T xi = sx[i];
+    if (pa == 0) Xc[((size_t)N * NX + i) * B] = xi;
+    T total = (T(0.5) * cx + T(0.5) * cu) * a.dt + T(0.5) * (xi - xti) * qf;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) total += shfl_xor_t(total, m);
+    if (lane == 0) a.costs[(size_t)ai * B + b] = total;
+}
+
+// ---------------------------------------------------------------------------
 // backward sweep: one wave per trajectory, tiles in LDS.
 // ---------------------------------------------------------------------------
+// out[r][c0 .. c0+W) (+)= sum_s X(r, s) * Y[s][c0 .. c0+W), operands in LDS, one strip of W consecutive
+// outputs per lane (W = R*C/64, or 1 with the upper lanes idle when R*C < 64).  XT: the left operand is
+// stored transposed (X(r, s) = Xm[s*R + r]), which is how f_x' V, f_u' V and Q_ux' K read it.
+template <typename T, int R, int K, int C, bool XT, typename Init>
+ILQR_DEV void lds_matmul(const T* Xm, const T* Ym, T* out, int lane, Init init) {
+    constexpr int TOT = R * C;
+    constexpr int W = TOT >= 64 ? TOT / 64 : 1;
+    static_assert(C % W == 0, "a strip must not cross a row");
+    const int o = lane * W;
+    if (o < TOT) {
+        const int r = o / C, c0 = o % C;
+        T acc[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) acc[w] = init(r, c0 + w);
+#pragma unroll
+        for (int s = 0; s < K; ++s) {
+            const T xv = XT ? Xm[s * R + r] : Xm[r * K + s];
+#pragma unroll
+            for (int w = 0; w < W; ++w) acc[w] += xv * Ym[s * C + c0 + w];
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) out[o + w] = acc[w];
+    }
+}
+
 template <typename T, int NX, int NU>
 __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
     constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
@@ -101,12 +240,11 @@ __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
     const size_t B = a.B;
     const int N = a.N;
 
-    __shared__ T tile[E];               // f_x f_u l_x l_u l_xx l_ux l_uu of the current step
-    __shared__ T V[NX * NX], Vx[NX];    // carried value function
-    __shared__ T P[NX * NX], Pu[NU * NX];
-    __shared__ T Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], Qx[NX], Qu[NU];
-    __shared__ T Lc[NU * NU], Z[NU * NRHS];  // Cholesky factor; solutions [K | k] (negated on use)
-    __shared__ int s_pd;
+    __shared__ __attribute__((aligned(16))) T tile[E + 4];  // f_x f_u l_x l_u l_xx l_ux l_uu of the current step
+    __shared__ __attribute__((aligned(16))) T V[NX * NX], Vx[NX];
+    __shared__ __attribute__((aligned(16))) T P[NX * NX], Pu[NU * NX];
+    __shared__ __attribute__((aligned(16))) T Qxx[NX * NX], Qux[NU * NX], Quu[NU * NU], Qx[NX], Qu[NU];
+    __shared__ __attribute__((aligned(16))) T Lc[NU * NU], Z[NU * NRHS];  // LU fallback scratch; [K | k]
 
     for (int e = lane; e < NX * NX; e += 64) V[e] = a.term[(size_t)(NX + e) * B + b];
     if (lane < NX) Vx[lane] = a.term[(size_t)lane * B + b];
@@ -119,8 +257,10 @@ __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
         pre[r] = e < E ? lin[(size_t)(N - 1) * tstride + e] : T(0);
     }
     bool all_pd = true;
+    const T* fx = tile;
+    const T* fu = tile + oFU;
     for (int t = N - 1; t >= 0; --t) {
-        // ---- phase 0: publish the prefetched record, request the next one -------------------
+        // ---- phase 0: publish the prefetched record, request the next one ---------------------------
 #pragma unroll
         for (int r = 0; r < PER; ++r) {
             const int e = lane + 64 * r;
@@ -133,169 +273,147 @@ __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
             pre[r] = e < E ? lin[(size_t)tn * tstride + e] : T(0);
         }
         __syncthreads();
-        // ---- phase 1: P = f_x' V ; Pu = f_u' V ; Q_x ; Q_u ------------------------------------
-        for (int e = lane; e < NX * NX; e += 64) {
-            const int i = e / NX, j = e % NX;
-            T acc = T(0);
-#pragma unroll 4
-            for (int s = 0; s < NX; ++s) acc += tile[s * NX + i] * V[s * NX + j];
-            P[e] = acc;
-        }
-        for (int e = lane; e < NU * NX; e += 64) {
-            const int i = e / NX, j = e % NX;
-            T acc = T(0);
-#pragma unroll 4
-            for (int s = 0; s < NX; ++s) acc += tile[oFU + s * NU + i] * V[s * NX + j];
-            Pu[e] = acc;
-        }
+        // ---- phase 1: P = f_x' V ; Pu = f_u' V ; Q_x = l_x + f_x' V_x ; Q_u = l_u + f_u' V_x --------------
+        lds_matmul<T, NX, NX, NX, true>(fx, V, P, lane, [](int, int) { return T(0); });
+        lds_matmul<T, NU, NX, NX, true>(fu, V, Pu, lane, [](int, int) { return T(0); });
         if (lane < NX) {
-            T acc = T(0);
-            for (int s = 0; s < NX; ++s) acc += tile[s * NX + lane] * Vx[s];
-            Qx[lane] = tile[oLX + lane] + acc;
+            T acc = tile[oLX + lane];
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += fx[s * NX + lane] * Vx[s];
+            Qx[lane] = acc;
         } else if (lane >= 32 && lane < 32 + NU) {
             const int j = lane - 32;
-            T acc = T(0);
-            for (int s = 0; s < NX; ++s) acc += tile[oFU + s * NU + j] * Vx[s];
-            Qu[j] = tile[oLU + j] + acc;
+            T acc = tile[oLU + j];
+#pragma unroll
+            for (int s = 0; s < NX; ++s) acc += fu[s * NU + j] * Vx[s];
+            Qu[j] = acc;
         }
         __syncthreads();
-        // ---- phase 2: Q_xx = l_xx + P f_x ; Q_ux = l_ux + Pu f_x ; Q_uu = l_uu + Pu f_u ---------
-        for (int e = lane; e < NX * NX; e += 64) {
-            const int i = e / NX, j = e % NX;
-            T acc = T(0);
-#pragma unroll 4
-            for (int s = 0; s < NX; ++s) acc += P[i * NX + s] * tile[s * NX + j];
-            Qxx[e] = tile[oLXX + e] + acc;
-        }
-        for (int e = lane; e < NU * NX; e += 64) {
-            const int i = e / NX, j = e % NX;
-            T acc = T(0);
-#pragma unroll 4
-            for (int s = 0; s < NX; ++s) acc += Pu[i * NX + s] * tile[s * NX + j];
-            Qux[e] = tile[oLUX + e] + acc;
-        }
-        for (int e = lane; e < NU * NU; e += 64) {
-            const int i = e / NU, j = e % NU;
-            T acc = T(0);
-#pragma unroll 4
-            for (int s = 0; s < NX; ++s) acc += Pu[i * NX + s] * tile[oFU + s * NU + j];
-            Quu[e] = tile[oLUU + e] + acc;
-        }
+        // ---- phase 2: Q_xx = l_xx + P f_x ; Q_ux = l_ux + Pu f_x ; Q_uu = l_uu + Pu f_u -------------------
+        lds_matmul<T, NX, NX, NX, false>(P, fx, Qxx, lane, [&](int r, int c) { return tile[oLXX + r * NX + c]; });
+        lds_matmul<T, NU, NX, NX, false>(Pu, fx, Qux, lane, [&](int r, int c) { return tile[oLUX + r * NX + c]; });
+        lds_matmul<T, NU, NX, NU, false>(Pu, fu, Quu, lane, [&](int r, int c) { return tile[oLUU + r * NU + c]; });
         __syncthreads();
-        // ---- phase 3: Cholesky of Q_uu + mu I (column by column, rows in parallel) ---------------
-        if (lane == 0) s_pd = 1;
+        // ---- phase 3: Cholesky of Q_uu + mu I, redundantly in every lane's registers (no barriers) -----------
+        T Lr[NU][NU];
+        bool pd = true;
+#pragma unroll
         for (int c = 0; c < NU; ++c) {
-            __syncthreads();
-            if (lane == 0) {
-                T d = Quu[c * NU + c] + a.mu;
-                for (int s = 0; s < c; ++s) d -= Lc[c * NU + s] * Lc[c * NU + s];
-                if (!(d > T(0))) s_pd = 0;
-                Lc[c * NU + c] = M<T>::sqrt(d);
-            }
-            __syncthreads();
-            if (lane > c && lane < NU) {
-                T v = Quu[lane * NU + c];
-                for (int s = 0; s < c; ++s) v -= Lc[lane * NU + s] * Lc[c * NU + s];
-                Lc[lane * NU + c] = v / Lc[c * NU + c];
+            T d = Quu[c * NU + c] + a.mu;
+#pragma unroll
+            for (int s2 = 0; s2 < c; ++s2) d -= Lr[c][s2] * Lr[c][s2];
+            pd = pd && (d > T(0));
+            const T lcc = M<T>::sqrt(d);
+            Lr[c][c] = lcc;
+            const T inv = T(1) / lcc;
+#pragma unroll
+            for (int i2 = c + 1; i2 < NU; ++i2) {
+                T v = Quu[i2 * NU + c];
+#pragma unroll
+                for (int s2 = 0; s2 < c; ++s2) v -= Lr[i2][s2] * Lr[c][s2];
+                Lr[i2][c] = v * inv;
             }
         }
-        __syncthreads();
-        const bool pd = s_pd != 0;
         all_pd = all_pd && pd;
-        // ---- phase 4: solve for [K | k]: one right-hand side per lane ----------------------------
+        // ---- phase 4: [K | k] = -(Q_uu + mu I)^-1 [Q_ux | Q_u], one right-hand side per lane ------------------
         if (pd) {
             if (lane < NRHS) {
                 T y[NU];
 #pragma unroll
-                for (int i = 0; i < NU; ++i) {
-                    T v = lane < NX ? Qux[i * NX + lane] : Qu[i];
+                for (int i2 = 0; i2 < NU; ++i2) {
+                    T v = lane < NX ? Qux[i2 * NX + lane] : Qu[i2];
 #pragma unroll
-                    for (int s = 0; s < i; ++s) v -= Lc[i * NU + s] * y[s];
-                    y[i] = v / Lc[i * NU + i];
+                    for (int s2 = 0; s2 < i2; ++s2) v -= Lr[i2][s2] * y[s2];
+                    y[i2] = v / Lr[i2][i2];
                 }
 #pragma unroll
-                for (int i = NU - 1; i >= 0; --i) {
-                    T v = y[i];
+                for (int i2 = NU - 1; i2 >= 0; --i2) {
+                    T v = y[i2];
 #pragma unroll
-                    for (int s = i + 1; s < NU; ++s) v -= Lc[s * NU + i] * y[s];
-                    y[i] = v / Lc[i * NU + i];
+                    for (int s2 = i2 + 1; s2 < NU; ++s2) v -= Lr[s2][i2] * y[s2];
+                    y[i2] = v / Lr[i2][i2];
                 }
 #pragma unroll
-                for (int i = 0; i < NU; ++i) Z[i * NRHS + lane] = -y[i];
+                for (int i2 = 0; i2 < NU; ++i2) Z[i2 * NRHS + lane] = -y[i2];
             }
         } else if (lane == 0) {
             // not positive definite: Gaussian elimination with partial pivoting, what the reference's
             // jnp.linalg.solve always does (iLQR_class.py:109-110); serial, rare
-            for (int i = 0; i < NU; ++i) {
-                for (int j = 0; j < NU; ++j) Lc[i * NU + j] = Quu[i * NU + j] + (i == j ? a.mu : T(0));
-                for (int j = 0; j < NX; ++j) Z[i * NRHS + j] = Qux[i * NX + j];
-                Z[i * NRHS + NX] = Qu[i];
+            for (int i2 = 0; i2 < NU; ++i2) {
+                for (int j2 = 0; j2 < NU; ++j2) Lc[i2 * NU + j2] = Quu[i2 * NU + j2] + (i2 == j2 ? a.mu : T(0));
+                for (int j2 = 0; j2 < NX; ++j2) Z[i2 * NRHS + j2] = Qux[i2 * NX + j2];
+                Z[i2 * NRHS + NX] = Qu[i2];
             }
             for (int k = 0; k < NU; ++k) {
                 int piv = k;
                 T best = M<T>::abs(Lc[k * NU + k]);
-                for (int i = k + 1; i < NU; ++i)
-                    if (M<T>::abs(Lc[i * NU + k]) > best) { best = M<T>::abs(Lc[i * NU + k]); piv = i; }
+                for (int i2 = k + 1; i2 < NU; ++i2)
+                    if (M<T>::abs(Lc[i2 * NU + k]) > best) { best = M<T>::abs(Lc[i2 * NU + k]); piv = i2; }
                 if (piv != k) {
-                    for (int j = 0; j < NU; ++j) { T w = Lc[k * NU + j]; Lc[k * NU + j] = Lc[piv * NU + j]; Lc[piv * NU + j] = w; }
-                    for (int j = 0; j < NRHS; ++j) { T w = Z[k * NRHS + j]; Z[k * NRHS + j] = Z[piv * NRHS + j]; Z[piv * NRHS + j] = w; }
+                    for (int j2 = 0; j2 < NU; ++j2) { T w = Lc[k * NU + j2]; Lc[k * NU + j2] = Lc[piv * NU + j2]; Lc[piv * NU + j2] = w; }
+                    for (int j2 = 0; j2 < NRHS; ++j2) { T w = Z[k * NRHS + j2]; Z[k * NRHS + j2] = Z[piv * NRHS + j2]; Z[piv * NRHS + j2] = w; }
                 }
-                for (int i = k + 1; i < NU; ++i) {
-                    const T l = Lc[i * NU + k] / Lc[k * NU + k];
-                    for (int j = k + 1; j < NU; ++j) Lc[i * NU + j] -= l * Lc[k * NU + j];
-                    for (int j = 0; j < NRHS; ++j) Z[i * NRHS + j] -= l * Z[k * NRHS + j];
+                for (int i2 = k + 1; i2 < NU; ++i2) {
+                    const T l = Lc[i2 * NU + k] / Lc[k * NU + k];
+                    for (int j2 = k + 1; j2 < NU; ++j2) Lc[i2 * NU + j2] -= l * Lc[k * NU + j2];
+                    for (int j2 = 0; j2 < NRHS; ++j2) Z[i2 * NRHS + j2] -= l * Z[k * NRHS + j2];
                 }
             }
             for (int k = NU - 1; k >= 0; --k)
-                for (int j = 0; j < NRHS; ++j) {
-                    T acc = Z[k * NRHS + j];
-                    for (int i = k + 1; i < NU; ++i) acc -= Lc[k * NU + i] * Z[i * NRHS + j];
-                    Z[k * NRHS + j] = acc / Lc[k * NU + k];
+                for (int j2 = 0; j2 < NRHS; ++j2) {
+                    T acc = Z[k * NRHS + j2];
+                    for (int i2 = k + 1; i2 < NU; ++i2) acc -= Lc[k * NU + i2] * Z[i2 * NRHS + j2];
+                    Z[k * NRHS + j2] = acc / Lc[k * NU + k];
                 }
-            for (int i = 0; i < NU * NRHS; ++i) Z[i] = -Z[i];
+            for (int i2 = 0; i2 < NU * NRHS; ++i2) Z[i2] = -Z[i2];
         }
         __syncthreads();
-        // ---- phase 5: gains out, value update (iLQR_class.py:113-114; full form when mu > 0) ---------
+        // ---- phase 5: gains out, value update (iLQR_class.py:113-114; full form when mu > 0) -------------------
         T* rec = a.gains + ((size_t)t * B + b) * R;
         for (int e = lane; e < NU * NX; e += 64) rec[e] = Z[(e / NX) * NRHS + (e % NX)];
         if (lane < NU) rec[NU * NX + lane] = Z[lane * NRHS + NX];
-        constexpr int VPER = (NX * NX + 63) / 64;
-        T vnew[VPER];
+        constexpr int VW = (NX * NX) / 64 > 0 ? (NX * NX) / 64 : 1;   // strip of V per lane
+        T vnew[VW];
+        const int vo = lane * VW;
+        if (vo < NX * NX) {
+            const int i2 = vo / NX, j0 = vo % NX;
 #pragma unroll
-        for (int r = 0; r < VPER; ++r) {
-            const int e = lane + 64 * r;
-            if (e >= NX * NX) break;
-            const int i = e / NX, j = e % NX;
-            T acc = T(0);
-            if (a.mu == T(0)) {
-                for (int s = 0; s < NU; ++s) acc += Qux[s * NX + i] * Z[s * NRHS + j];
-            } else {
-                for (int s = 0; s < NU; ++s) {
-                    T qk = T(0);  // (Q_uu K)[s][j]
-                    for (int q = 0; q < NU; ++q) qk += Quu[s * NU + q] * Z[q * NRHS + j];
-                    acc += Z[s * NRHS + i] * (qk + Qux[s * NX + j]) + Qux[s * NX + i] * Z[s * NRHS + j];
+            for (int w = 0; w < VW; ++w) {
+                const int j2 = j0 + w;
+                T acc = T(0);
+                if (a.mu == T(0)) {
+#pragma unroll
+                    for (int s2 = 0; s2 < NU; ++s2) acc += Qux[s2 * NX + i2] * Z[s2 * NRHS + j2];
+                } else {
+                    for (int s2 = 0; s2 < NU; ++s2) {
+                        T qk = T(0);  // (Q_uu K)[s][j]
+                        for (int q = 0; q < NU; ++q) qk += Quu[s2 * NU + q] * Z[q * NRHS + j2];
+                        acc += Z[s2 * NRHS + i2] * (qk + Qux[s2 * NX + j2]) + Qux[s2 * NX + i2] * Z[s2 * NRHS + j2];
+                    }
                 }
+                vnew[w] = Qxx[vo + w] + acc;
             }
-            vnew[r] = Qxx[e] + acc;
         }
         T vxnew = T(0);
         if (lane < NX) {
             T acc = T(0);
             if (a.mu == T(0)) {
-                for (int s = 0; s < NU; ++s) acc += Z[s * NRHS + lane] * Qu[s];
+#pragma unroll
+                for (int s2 = 0; s2 < NU; ++s2) acc += Z[s2 * NRHS + lane] * Qu[s2];
             } else {
-                for (int s = 0; s < NU; ++s) {
+                for (int s2 = 0; s2 < NU; ++s2) {
                     T qk = T(0);  // (Q_uu k)[s]
-                    for (int q = 0; q < NU; ++q) qk += Quu[s * NU + q] * Z[q * NRHS + NX];
-                    acc += Z[s * NRHS + lane] * (qk + Qu[s]) + Qux[s * NX + lane] * Z[s * NRHS + NX];
+                    for (int q = 0; q < NU; ++q) qk += Quu[s2 * NU + q] * Z[q * NRHS + NX];
+                    acc += Z[s2 * NRHS + lane] * (qk + Qu[s2]) + Qux[s2 * NX + lane] * Z[s2 * NRHS + NX];
                 }
             }
             vxnew = Qx[lane] + acc;
         }
         __syncthreads();
+        if (vo < NX * NX) {
 #pragma unroll
-        for (int r = 0; r < VPER; ++r)
-            if (lane + 64 * r < NX * NX) V[lane + 64 * r] = vnew[r];
+            for (int w = 0; w < VW; ++w) V[vo + w] = vnew[w];
+        }
         if (lane < NX) Vx[lane] = vxnew;
         __syncthreads();
     }

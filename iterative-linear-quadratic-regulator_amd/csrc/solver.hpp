@@ -184,13 +184,20 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
             ILQR_LAUNCH((linearize_wave_kernel<T, NX, NU>), dim3((unsigned)((size_t)a.B * (a.N + 1))), dim3(64), 0, s, a);
         };
     }
-    o.forward[ILQR_INT_EULER] = [](const KArgs<T>& a, hipStream_t s) {
-        ILQR_LAUNCH((forward_kernel<T, Dyn, ILQR_INT_EULER>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
-    };
-    o.forward[ILQR_INT_DISCRETE] = [](const KArgs<T>& a, hipStream_t s) {
-        ILQR_LAUNCH((forward_kernel<T, Dyn, ILQR_INT_DISCRETE>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
-    };
-    o.forward[ILQR_INT_MIDPOINT] = o.forward[ILQR_INT_RK4] = o.forward[ILQR_INT_BACKWARD_EULER] = o.forward[ILQR_INT_EULER];
+    for (int k = 0; k < 5; ++k) {
+        // euler / discrete are told apart inside the kernel (a.integ); the others do not exist for n_x > 4
+        o.forward[k] = [](const KArgs<T>& a, hipStream_t s) {
+            static const bool plain = getenv("ILQR_FORWARD_PLAIN") != nullptr;   // A/B: lane-per-rollout kernel
+            if (plain) {
+                if (a.integ == ILQR_INT_DISCRETE)
+                    ILQR_LAUNCH((forward_kernel<T, Dyn, ILQR_INT_DISCRETE>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+                else
+                    ILQR_LAUNCH((forward_kernel<T, Dyn, ILQR_INT_EULER>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
+                return;
+            }
+            ILQR_LAUNCH((forward_wave_kernel<T, NX, NU>), dim3(a.B, a.n_pass), dim3(64), 0, s, a);
+        };
+    }
     o.backward = [](const KArgs<T>& a, hipStream_t s) {
         ILQR_LAUNCH((backward_wave_kernel<T, NX, NU>), dim3(a.B), dim3(64), 0, s, a);
     };
