@@ -168,7 +168,7 @@ def main():
     def fence():
         if world > 1:
             xchg.result()            # the last exchange has landed on every rank
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -253,7 +253,7 @@ def main():
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
