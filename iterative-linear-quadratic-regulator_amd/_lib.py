@@ -22,7 +22,7 @@ CSRC = os.path.join(HERE, "csrc")
 # ---- enums (include/ilqr_hip.h) --------------------------------------------------
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_STATE = range(6)
 F32, F64 = 0, 1
-SYS_PENDULUM, SYS_UA_DOUBLE_PENDULUM, SYS_DOUBLE_PENDULUM, SYS_LINEAR = range(4)
+SYS_PENDULUM, SYS_UA_DOUBLE_PENDULUM, SYS_DOUBLE_PENDULUM, SYS_LINEAR, SYS_CUSTOM = range(5)
 INTEGRATORS = {"euler": 0, "midpoint": 1, "rk4": 2, "backward_euler": 3, "discrete": 4}
 (X, U, K, UFF, X0, COST, STATUS, ITERS, ALPHA, TRIAL_COSTS, LIN, PLANT_X, PROBE) = range(13)
 TRAJ_ACTIVE, TRAJ_CONVERGED, TRAJ_LINESEARCH_FAILED, TRAJ_MAXITER = range(4)
@@ -34,7 +34,7 @@ ABI_VERSION = 1
 # every symbol include/ilqr_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "ilqr_abi_version", "ilqr_device_count", "ilqr_param_count", "ilqr_is_supported", "ilqr_last_error",
-    "ilqr_create", "ilqr_destroy", "ilqr_sync", "ilqr_set_problem", "ilqr_set", "ilqr_get",
+    "ilqr_create", "ilqr_create_custom", "ilqr_destroy", "ilqr_sync", "ilqr_set_problem", "ilqr_set", "ilqr_get",
     "ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_forward", "ilqr_select", "ilqr_iterate",
     "ilqr_solve", "ilqr_backward_pass", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
     "ilqr_mpc_run", "ilqr_status_reduce", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
@@ -95,6 +95,7 @@ def load():
     lib.ilqr_last_error.argtypes = [vp]
     lib.ilqr_last_error.restype = C.c_char_p
     lib.ilqr_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+    lib.ilqr_create_custom.argtypes = [C.POINTER(vp), C.POINTER(Config), C.c_char_p]
     lib.ilqr_destroy.argtypes = [vp]
     lib.ilqr_sync.argtypes = [vp]
     lib.ilqr_set_problem.argtypes = [vp, vp, vp]
@@ -144,7 +145,7 @@ class Handle:
 
     def __init__(self, *, system, n_x, n_u, horizon, batch, params, dt, integrator, dtype=np.float64,
                  n_alpha=10, n_trials=10, tol=1e-5, maxiter=100, alpha_factor=0.5, min_alpha=1e-8, mu=0.0,
-                 plant_integrator=None, device=0, flags=0, stream=None):
+                 plant_integrator=None, device=0, flags=0, stream=None, plugin=None):
         self.lib = load()
         self.np_dtype, dcode = np_dtype(dtype)
         if isinstance(integrator, str):
@@ -170,7 +171,10 @@ class Handle:
         cfg.n_params = p.size
         cfg.stream = stream
         h = C.c_void_p()
-        rc = self.lib.ilqr_create(C.byref(h), C.byref(cfg))
+        if plugin is not None:  # user-defined system: kernels live in the plugin (systems/custom_sys.py)
+            rc = self.lib.ilqr_create_custom(C.byref(h), C.byref(cfg), os.fsencode(plugin))
+        else:
+            rc = self.lib.ilqr_create(C.byref(h), C.byref(cfg))
         if rc != OK:
             msg = self.lib.ilqr_last_error(None).decode()
             if rc == ERR_INVALID_ARG:

@@ -287,10 +287,16 @@ ILQR_DEV void lu_solve_inplace(T (*A)[N], T (*rhs)[NR]) {
 // ---------------------------------------------------------------------------
 // integrators (system_base.py:50-140) and their discrete Jacobians
 // ---------------------------------------------------------------------------
+// which systems get the multi-stage / implicit integrators: n_x <= 4 by default (the big linear systems only
+// get the closed-form ones: register budget), or any Dyn that asks for them (user-defined plugins)
+template <typename Dyn, typename = void> struct all_integrators { static constexpr bool value = (Dyn::NX <= 4); };
+template <typename Dyn> struct all_integrators<Dyn, decltype((void)Dyn::ALL_INTEGRATORS)> {
+    static constexpr bool value = Dyn::ALL_INTEGRATORS;
+};
+
 template <typename T, typename Dyn> struct Stepper {
     static constexpr int NX = Dyn::NX, NU = Dyn::NU;
-    // big linear systems only get the closed-form integrators (register budget)
-    static constexpr bool SMALL = (NX <= 4);
+    static constexpr bool SMALL = all_integrators<Dyn>::value;
 
     // backward Euler quasi-Newton (system_base.py:88-140): explicit-Euler guess, one
     // Jacobian I - dt*J_x at the guess reused, stop at ||F||_2 <= 1e-5 or 20 iterations.

@@ -4,6 +4,8 @@
 // system_base.py:198) come back as ILQR_ERR_INVALID_ARG before anything touches the GPU.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cstring>
 #include <string>
 
@@ -17,6 +19,7 @@ int n_sys_params_abi(int system, int n_x, int n_u) {
         case ILQR_SYS_UA_DOUBLE_PENDULUM: return (n_x == 4 && n_u == 1) ? 9 : -1;
         case ILQR_SYS_DOUBLE_PENDULUM: return (n_x == 4 && n_u == 2) ? 9 : -1;
         case ILQR_SYS_LINEAR: return (n_x >= 1 && n_u >= 1 && n_x <= 64 && n_u <= 64) ? n_x * n_x + n_x * n_u : -1;
+        case ILQR_SYS_CUSTOM: return (n_x >= 1 && n_u >= 1 && n_x <= 6 && n_u <= n_x) ? 0 : -1;
         default: return -1;
     }
 }
@@ -33,6 +36,7 @@ using ilqr::SolverBase;
 
 struct ilqr_solver_s {
     SolverBase* impl;
+    void* plugin;  // dlopen handle of a user-system plugin, or nullptr
 };
 
 static thread_local std::string g_create_error;
@@ -68,7 +72,7 @@ const char* ilqr_last_error(ilqr_handle h) {
     return h->impl->err.c_str();
 }
 
-int ilqr_create(ilqr_handle* out, const ilqr_config* cfg) {
+static int create_impl(ilqr_handle* out, const ilqr_config* cfg, const char* plugin_path) {
     if (!out) return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create: out is NULL");
     *out = nullptr;
     if (!cfg) return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create: cfg is NULL");
@@ -97,12 +101,14 @@ int ilqr_create(ilqr_handle* out, const ilqr_config* cfg) {
         return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create: unknown system or n_x/n_u do not match the system");
     if (!cfg->params || cfg->n_params != want)
         return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create: params is NULL or n_params != ilqr_param_count()");
-    if (!ilqr_is_supported(cfg->system, cfg->n_x, cfg->n_u, cfg->dtype))
+    if ((cfg->system == ILQR_SYS_CUSTOM) != (plugin_path != nullptr))
+        return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create: ILQR_SYS_CUSTOM goes through ilqr_create_custom (and only it)");
+    if (!plugin_path && !ilqr_is_supported(cfg->system, cfg->n_x, cfg->n_u, cfg->dtype))
         return fail_create(ILQR_ERR_UNSUPPORTED, "ilqr_create: no kernels compiled for this (system, n_x, n_u, dtype)");
     if ((cfg->integrator == ILQR_INT_MIDPOINT || cfg->integrator == ILQR_INT_RK4 ||
          cfg->integrator == ILQR_INT_BACKWARD_EULER || cfg->plant_integrator == ILQR_INT_MIDPOINT ||
          cfg->plant_integrator == ILQR_INT_RK4 || cfg->plant_integrator == ILQR_INT_BACKWARD_EULER) &&
-        cfg->n_x > 4)
+        cfg->n_x > 4 && !plugin_path)
         return fail_create(ILQR_ERR_UNSUPPORTED, "ilqr_create: n_x > 4 supports the 'euler' and 'discrete' integrators only");
 
     // the product path has no CPU fallback: a gfx950 device is mandatory
@@ -120,18 +126,57 @@ int ilqr_create(ilqr_handle* out, const ilqr_config* cfg) {
 
     std::string err;
     int status = ILQR_OK;
-    SolverBase* impl = (cfg->dtype == ILQR_F32) ? ilqr::make_solver_f32(*cfg, err, &status)
-                                                : ilqr::make_solver_f64(*cfg, err, &status);
-    if (!impl) return fail_create(status ? status : ILQR_ERR_HIP, err);
+    SolverBase* impl = nullptr;
+    void* plugin = nullptr;
+    if (plugin_path) {
+        // user-defined system: the plugin holds the kernels instantiated for the generated dynamics
+        plugin = dlopen(plugin_path, RTLD_NOW | RTLD_LOCAL);
+        if (!plugin) return fail_create(ILQR_ERR_INVALID_ARG, std::string("ilqr_create_custom: dlopen failed: ") + dlerror());
+        typedef int (*info_fn)(int*, int*, int*);
+        typedef SolverBase* (*make_fn)(const ilqr_config*, char*, int, int*);
+        info_fn info = (info_fn)dlsym(plugin, "ilqr_plugin_info");
+        make_fn make = (make_fn)dlsym(plugin, "ilqr_plugin_make_solver");
+        int abi = 0, pnx = 0, pnu = 0;
+        if (!info || !make || info(&abi, &pnx, &pnu) != 0 || abi != ILQR_ABI_VERSION) {
+            dlclose(plugin);
+            return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create_custom: not an ilqr system plugin of this ABI version");
+        }
+        if (pnx != cfg->n_x || pnu != cfg->n_u) {
+            dlclose(plugin);
+            return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create_custom: n_x / n_u do not match the plugin's system");
+        }
+        char msg[512] = {0};
+        impl = make(cfg, msg, (int)sizeof(msg), &status);
+        if (!impl) {
+            dlclose(plugin);
+            return fail_create(status ? status : ILQR_ERR_HIP, msg);
+        }
+    } else {
+        impl = (cfg->dtype == ILQR_F32) ? ilqr::make_solver_f32(*cfg, err, &status) : ilqr::make_solver_f64(*cfg, err, &status);
+        if (!impl) return fail_create(status ? status : ILQR_ERR_HIP, err);
+    }
     impl->cfg.params = nullptr;  // never retain the caller's host pointer
-    ilqr_handle h = new ilqr_solver_s{impl};
+    ilqr_handle h = new ilqr_solver_s{impl, plugin};
     *out = h;
     return ILQR_OK;
 }
 
+int ilqr_create(ilqr_handle* out, const ilqr_config* cfg) { return create_impl(out, cfg, nullptr); }
+
+int ilqr_create_custom(ilqr_handle* out, const ilqr_config* cfg, const char* plugin_path) {
+    if (!plugin_path) {
+        if (out) *out = nullptr;
+        return fail_create(ILQR_ERR_INVALID_ARG, "ilqr_create_custom: plugin_path is NULL");
+    }
+    return create_impl(out, cfg, plugin_path);
+}
+
+
+
 int ilqr_destroy(ilqr_handle h) {
     if (!h) return ILQR_OK;
-    delete h->impl;
+    delete h->impl;  // its code lives in the plugin: destroy before unloading
+    if (h->plugin) dlclose(h->plugin);
     delete h;
     return ILQR_OK;
 }

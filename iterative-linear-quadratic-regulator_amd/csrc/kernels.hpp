@@ -578,7 +578,12 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     using In = FwdIn<T, NX, NU>;
     constexpr int R = In::R, NLD = In::NLD, NST = NX + NU;
-    constexpr int PF = (63 / (NLD + NST)) + 1 > 6 ? 6 : (63 / (NLD + NST)) + 1;   // (PF-1)*(NLD+NST) <= 63
+    // ring depth: (PF-1)*(NLD+NST) <= 63 (the vmcnt field), at most 6, and at most ~130 VGPRs of ring so the
+    // rollout arithmetic still fits the 256 without spilling (see csrc/check_ring_kernels.py)
+    constexpr int SLOT_REGS = (NX + NU + R) * (int)sizeof(T) / 4;
+    constexpr int PF_CNT = (63 / (NLD + NST)) + 1 > 6 ? 6 : (63 / (NLD + NST)) + 1;
+    constexpr int PF = PF_CNT * SLOT_REGS > 130 ? 130 / SLOT_REGS : PF_CNT;
+    static_assert(PF >= 2, "ring too shallow to be worth it");
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int ai = blockIdx.y;
     const bool live = b < a.B && traj_active(a.status[b < a.B ? b : 0]) && !a.accepted[b < a.B ? b : 0];

@@ -96,8 +96,20 @@ template <typename T> struct Ops {
 
 // linearize / forward are compiled once per integrator so the integrator switch folds away and each
 // variant gets its own register allocation (the RK4 rollout must not pay for the backward-Euler LU).
+// is there a generated FwdIn<T, NX, NU> (the ring rollout's one-statement load group) for these dimensions?
+template <typename T, int NX, int NU, typename = void> struct has_fwd_in { static constexpr bool value = false; };
+template <typename T, int NX, int NU> struct has_fwd_in<T, NX, NU, decltype((void)sizeof(FwdIn<T, NX, NU>))> {
+    static constexpr bool value = true;
+};
+
+// Bit i set: integrator i may use the ring rollout.  A plugin whose generated dynamics make a ring kernel spill
+// is recompiled with that integrator's bit cleared (csrc/check_ring_kernels.py, systems/custom_sys.py).
+#ifndef ILQR_RING_INTEG_MASK
+#define ILQR_RING_INTEG_MASK 0x1f
+#endif
+
 template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_ops(Ops<T>& o) {
-    constexpr bool SMALL = Dyn::NX <= 4;
+    constexpr bool SMALL = all_integrators<Dyn>::value;
     // n_x > 4 only has the closed-form integrators: fold the others onto euler so nothing big is compiled
     constexpr int I = (SMALL || INTEG == ILQR_INT_DISCRETE) ? INTEG : ILQR_INT_EULER;
     o.linearize[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
@@ -107,7 +119,7 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
     };
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
         const dim3 grid((a.B + 63) / 64, a.n_pass), block(64);
-        if constexpr (SMALL) {
+        if constexpr (has_fwd_in<T, Dyn::NX, Dyn::NU>::value && ((ILQR_RING_INTEG_MASK >> I) & 1)) {
             // ring form: 32-bit buffer offsets into X (the largest tensor), and a switch for A/B runs
             static const bool plain = getenv("ILQR_FORWARD_PLAIN") != nullptr;
             const bool fits = (size_t)a.n_slots * (a.N + 1) * Dyn::NX * a.B * sizeof(T) < (1ull << 31);
@@ -233,6 +245,8 @@ inline std::vector<double> build_device_params(int system, int nx, int nu, const
              d1,
              d2};
         q = p + 9;
+    } else if (system == ILQR_SYS_CUSTOM) {
+        q = p;  // user-defined dynamics carry their constants in the generated code
     } else {  // linear: A, B verbatim
         d.assign(p, p + nx * nx + nx * nu);
         q = p + nx * nx + nx * nu;
@@ -386,12 +400,16 @@ template <typename T> class SolverT : public SolverBase {
         return ILQR_OK;
     }
 
-    int init(const ilqr_config& c) {
+    // preset: the kernel set of a user-defined system compiled into a plugin (csrc/plugin_template.hip.in);
+    // nullptr: one of the built-in systems of this library
+    int init(const ilqr_config& c, const Ops<T>* preset = nullptr) {
         cfg = c;
         B = c.batch; N = c.horizon; NX = c.n_x; NU = c.n_u; A = c.n_alpha;
         E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
         R = gain_record(NX, NU);
-        if (!find_ops<T>(c.system, NX, NU, &ops)) {
+        if (preset) {
+            ops = *preset;
+        } else if (!find_ops<T>(c.system, NX, NU, &ops)) {
             err = "no kernels compiled for this (system, n_x, n_u, dtype)";
             return ILQR_ERR_UNSUPPORTED;
         }

@@ -64,8 +64,7 @@ class iLQR:
         if x_0.shape[-1] != self.n_x:
             raise ValueError(f"x_0 must have {self.n_x} components, but got shape {x_0.shape}")
 
-        if plant is not None and (type(plant) is not type(system) or
-                                  not np.array_equal(plant.param_block(), system.param_block())
+        if plant is not None and (type(plant) is not type(system) or not system.same_dynamics(plant)
                                   or plant.dt != system.dt):
             raise ValueError("the MPC plant must be the same system with the same parameters "
                              "(only its integrator may differ, run_iLQR_MPC.py:58-75)")

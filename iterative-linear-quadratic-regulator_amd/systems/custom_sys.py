@@ -1,0 +1,213 @@
+"""User-defined systems: the reference's subclass contract on the GPU.
+
+Reference: python/class_files/systems/system_base.py:255-275 -- a user subclasses
+``System``, writes ``_f_cont_fcn(self, x, u)`` (plus the costs) with ``jax.numpy`` math, and
+the base class traces it with JAX and differentiates it (``jacfwd``, :203-219).  Here the
+same method is written with ``sympy`` math (``from sympy import sin, cos``; everything else --
+arithmetic, indexing ``x[0]``, python floats for the constants -- is unchanged).  It is traced
+once with symbols, differentiated symbolically (``f_c``, ``df_c/dx``, ``df_c/du``), printed as
+a ``Dyn`` struct into csrc/plugin_template.hip.in and compiled with hipcc against the SAME
+kernel templates the built-in systems use (integrators and their chain-rule Jacobians, the
+n_x = 4 / n_u = 1 DPP backward sweep, the ring rollout, the solver).  The resulting plugin is
+loaded through ``ilqr_create_custom`` (include/ilqr_hip.h).
+
+Scope (this round): n_x <= 6, n_u <= n_x, and the quadratic cost every reference system uses
+(pendulum_sys.py:77-98) given as ``x_target, Q, R, Q_f``; a user ``_l_fcn`` is not traced yet.
+There is no interpreter fallback: without hipcc the plugin cannot be built and construction of
+a handle raises.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+
+from .. import _lib
+from .system_base import System
+
+PLUGIN_ROOT = os.path.join(_lib.HERE, "_plugins")
+TEMPLATE = os.path.join(_lib.CSRC, "plugin_template.hip.in")
+_KERNEL_HEADERS = ("dynamics.hpp", "kernels.hpp", "backward_tile16.hpp", "kernels_wave.hpp", "fwd_in_gen.inc",
+                   "solver.hpp", "plugin_template.hip.in")
+
+
+def _printer(n_x, n_u):
+    from sympy.printing.c import C99CodePrinter
+
+    class DevicePrinter(C99CodePrinter):
+        """C99 printer whose literals are typed ``T(...)`` (no silent promotion of fp32 arithmetic to
+        double) and whose math functions resolve to the plugin's ``um::`` overloads."""
+        _ns = "um::"
+
+        def _print_Float(self, e):
+            return f"T({float(e)!r})"
+
+        def _print_Rational(self, e):
+            return f"T({int(e.p)}.0 / {int(e.q)}.0)"
+
+        def _print_Integer(self, e):
+            return f"T({int(e)})"
+
+        def _print_NumberSymbol(self, e):
+            return f"T({float(e.evalf(17))!r})"
+
+        _print_Pi = _print_Exp1 = _print_NumberSymbol
+
+        def _print_Pow(self, e):
+            base, ex = e.base, e.exp
+            b = self.parenthesize(base, 1000)
+            if ex.is_Integer and 1 <= abs(int(ex)) <= 4:
+                prod = " * ".join([b] * abs(int(ex)))
+                return f"({prod})" if int(ex) > 0 else f"(T(1) / ({prod}))"
+            if ex == sp_half():
+                return f"um::sqrt({self._print(base)})"
+            if ex == -sp_half():
+                return f"(T(1) / um::sqrt({self._print(base)}))"
+            return f"um::pow({self._print(base)}, {self._print(ex)})"
+
+    return DevicePrinter()
+
+
+def sp_half():
+    import sympy as sp
+    return sp.Rational(1, 2)
+
+
+def generate_dyn_bodies(f_cont, n_x, n_u):
+    """Trace ``f_cont(x, u)`` with sympy symbols; returns (f_body, fjac_body) C++ statement blocks."""
+    import sympy as sp
+    xs = sp.symbols(f"x_0:{n_x}", real=True)
+    us = sp.symbols(f"u_0:{n_u}", real=True)
+    out = f_cont(list(xs), list(us))
+    out = [sp.sympify(e) for e in (out.tolist() if hasattr(out, "tolist") else list(out))]
+    out = [e[0] if isinstance(e, (list, tuple)) else e for e in out]
+    if len(out) != n_x:
+        raise ValueError(f"_f_cont_fcn returned {len(out)} components, expected n_x = {n_x}")
+    free = set().union(*[e.free_symbols for e in out]) - set(xs) - set(us)
+    if free:
+        raise ValueError(f"_f_cont_fcn has free symbols other than x, u: {sorted(map(str, free))}")
+    names = {**{s: f"x[{i}]" for i, s in enumerate(xs)}, **{s: f"u[{i}]" for i, s in enumerate(us)}}
+    pr = _printer(n_x, n_u)
+    pr._print_Symbol = lambda s: names.get(s, s.name)  # cse temporaries keep their own names
+
+    def block(targets):
+        repl, red = sp.cse([e for _, e in targets], symbols=sp.numbered_symbols("w_"), optimizations="basic")
+        lines = [f"        const T {pr.doprint(s)} = {pr.doprint(e)};" for s, e in repl]
+        lines += [f"        {name} = {pr.doprint(e)};" for (name, _), e in zip(targets, red)]
+        return "\n".join(lines)
+
+    f_targets = [(f"xd[{i}]", e) for i, e in enumerate(out)]
+    jac = list(f_targets)
+    jac += [(f"Jx[{i}][{j}]", sp.diff(out[i], xs[j])) for i in range(n_x) for j in range(n_x)]
+    jac += [(f"Ju[{i}][{j}]", sp.diff(out[i], us[j])) for i in range(n_x) for j in range(n_u)]
+    return block(f_targets), block(jac)
+
+
+def render_plugin_source(f_cont, n_x, n_u, dtype):
+    f_body, fjac_body = generate_dyn_bodies(f_cont, n_x, n_u)
+    src = open(TEMPLATE).read()
+    for key, val in (("@NX@", str(n_x)), ("@NU@", str(n_u)), ("@F_BODY@", f_body), ("@FJAC_BODY@", fjac_body),
+                     ("@DTYPE@", "float" if np.dtype(dtype) == np.float32 else "double")):
+        src = src.replace(key, val)
+    return src
+
+
+def build_plugin(source, verbose=False):
+    """Compile a generated plugin for gfx950 (in-tree, keyed by source + kernel headers); returns the .so path."""
+    h = hashlib.sha256(source.encode())
+    for name in _KERNEL_HEADERS:
+        h.update(open(os.path.join(_lib.CSRC, name), "rb").read())
+    h.update(open(os.path.join(_lib.HERE, "..", "include", "ilqr_hip.h"), "rb").read())
+    tag = h.hexdigest()[:16]
+    d = os.path.join(PLUGIN_ROOT, tag)
+    so = os.path.join(d, "ilqr_system_plugin.so")
+    if os.path.exists(so):
+        return so
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: a user-defined system needs it to compile its device code "
+                           "(there is no interpreter / CPU fallback)")
+    os.makedirs(d, exist_ok=True)
+    hip = os.path.join(d, "plugin.hip")
+    with open(hip, "w") as fh:
+        fh.write(source)
+    tmp = so + f".tmp{os.getpid()}"
+    sys.path.insert(0, _lib.CSRC)
+    try:
+        import check_ring_kernels as crk
+    finally:
+        sys.path.pop(0)
+    base = [hipcc, "-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fvisibility=hidden",
+            "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage", "-I", _lib.CSRC,
+            "-I", os.path.join(_lib.HERE, "..", "include"), "-o", tmp, hip]
+    mask = 0x1F
+    for attempt in range(2):
+        r = subprocess.run(base + [f"-DILQR_RING_INTEG_MASK={mask}"], capture_output=True, text=True)
+        if r.returncode != 0:
+            print(r.stderr[-8000:])
+            raise RuntimeError(f"compiling the system plugin failed ({hip})")
+        # the ring kernels count their own memory operations and must not spill (check_ring_kernels.py): route
+        # the integrators whose rollout does to the compiler-scheduled kernel and compile once more
+        bad = crk.violations(crk.parse(r.stderr))
+        if verbose:
+            print(f"plugin {tag}: ring mask {mask:#x}, spilling ring kernels: {[k['name'] for k in bad]}")
+        if not bad:
+            break
+        integ = [crk.forward_ring_integrator(k["name"]) for k in bad]
+        if attempt == 1 or any(i is None for i in integ):
+            raise RuntimeError("a self-counted ring kernel spills in this plugin build: " + ", ".join(k["name"] for k in bad))
+        for i in integ:
+            mask &= ~(1 << i)
+    with open(os.path.join(d, "ring_mask.txt"), "w") as fh:
+        fh.write(f"{mask:#x}\n")
+    os.replace(tmp, so)  # atomic: concurrent ranks building the same system never load a partial file
+    return so
+
+
+class SymbolicSystem(System):
+    """Base class for user-defined systems.
+
+    Subclass it, call ``super().__init__(n_x, n_u, dt, x_target, Q, R, Q_f, ...)`` and implement
+    ``_f_cont_fcn(self, x, u) -> sequence of n_x expressions`` with sympy math.  All twelve public
+    callables (``f_fcn`` ... ``l_f_xx_fcn``), ``iLQR(system, ...)``, ``solve`` and the MPC loop then work
+    as for the built-in systems.
+    """
+
+    SYSTEM_ID = _lib.SYS_CUSTOM
+
+    def __init__(self, n_x, n_u, dt, x_target, Q, R, Q_f, use_jit=True, integrator="rk4", dtype=np.float64):
+        super().__init__(n_x, n_u, dt, use_jit=use_jit, integrator=integrator, dtype=dtype)
+        if not (1 <= self.n_x <= 6 and 1 <= self.n_u <= self.n_x):
+            raise ValueError("user-defined systems support 1 <= n_u <= n_x <= 6")
+        self._set_cost(x_target, Q, R, Q_f)
+        self._plugins = {}
+
+    def _f_cont_fcn(self, x, u):
+        raise NotImplementedError("subclasses implement the continuous dynamics x_dot = f_c(x, u) (system_base.py:255)")
+
+    def _system_params(self):
+        return []  # the constants are part of the generated code
+
+    def same_dynamics(self, other):
+        return (super().same_dynamics(other) and
+                generate_dyn_bodies(self._f_cont_fcn, self.n_x, self.n_u) ==
+                generate_dyn_bodies(other._f_cont_fcn, other.n_x, other.n_u))
+
+    def plugin_source(self, dtype=None):
+        return render_plugin_source(self._f_cont_fcn, self.n_x, self.n_u, self.dtype if dtype is None else dtype)
+
+    def plugin_path(self, dtype=None, verbose=False):
+        dt = np.dtype(self.dtype if dtype is None else dtype)
+        if dt not in self._plugins:
+            self._plugins[dt] = build_plugin(self.plugin_source(dt), verbose=verbose)
+        return self._plugins[dt]
+
+    def make_handle(self, horizon, batch, dtype=None, **kw):
+        dt = self.dtype if dtype is None else dtype
+        return _lib.Handle(system=self.SYSTEM_ID, n_x=self.n_x, n_u=self.n_u, horizon=horizon, batch=batch,
+                           params=self.param_block(), dt=self.dt, integrator=self.integrator, dtype=dt,
+                           plugin=self.plugin_path(dt), **kw)

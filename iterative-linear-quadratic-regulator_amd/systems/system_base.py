@@ -69,6 +69,10 @@ class System:
                  np.asarray(self.Q_f, dtype=np.float64).reshape(n * n)]
         return np.concatenate(parts)
 
+    def same_dynamics(self, other):
+        """Same continuous dynamics and cost (the MPC plant may differ from the model in its integrator only)."""
+        return np.array_equal(self.param_block(), other.param_block())
+
     def _set_cost(self, x_target, Q, R, Q_f):
         n, m = self.n_x, self.n_u
         self.x_target = np.asarray(x_target, dtype=np.float64).reshape(n)
