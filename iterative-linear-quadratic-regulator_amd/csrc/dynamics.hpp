@@ -507,73 +507,130 @@ template <typename T, typename Dyn> struct Stepper {
 };
 
 // ---------------------------------------------------------------------------
-// quadratic costs (pendulum_sys.py:77-98, UA_double_pendulum_sys.py:114-136)
+// costs.  Built-in systems: the quadratic forms of pendulum_sys.py:77-98 / UA_double_pendulum_sys.py:114-136,
+// read from the parameter block.  A Dyn with CUSTOM_COST (a user system whose _l_fcn / _l_f_fcn were traced,
+// system_base.py:262-275) supplies l, lf and their first and second derivatives as generated code instead;
+// like the reference's _l_fcn it returns the stage cost as the user wrote it (dt scaling included or not).
 // ---------------------------------------------------------------------------
+template <typename Dyn, typename = void> struct has_custom_cost { static constexpr bool value = false; };
+template <typename Dyn> struct has_custom_cost<Dyn, decltype((void)Dyn::CUSTOM_COST)> {
+    static constexpr bool value = Dyn::CUSTOM_COST;
+};
+
 template <typename T, typename Dyn> struct Cost {
     static constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    static constexpr bool CUSTOM = has_custom_cost<Dyn>::value;
     using L = ParamLayout<Dyn::NSYS, NX, NU>;
 
     // l(x,u) = (0.5 dx'Q dx + 0.5 u'R u) * dt
     static ILQR_DEV T stage(const T* __restrict__ p, T dt, const T* x, const T* u) {
-        T dx[NX];
+        if constexpr (CUSTOM) {
+            return Dyn::l(x, u);
+        } else {
+            T dx[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = x[i] - p[L::XT + i];
-        T cx = T(0), cu = T(0);
+            for (int i = 0; i < NX; ++i) dx[i] = x[i] - p[L::XT + i];
+            T cx = T(0), cu = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            T r = T(0);
+            for (int i = 0; i < NX; ++i) {
+                T r = T(0);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r += p[L::Q + i * NX + j] * dx[j];
-            cx += dx[i] * r;
+                for (int j = 0; j < NX; ++j) r += p[L::Q + i * NX + j] * dx[j];
+                cx += dx[i] * r;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                T r = T(0);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) r += p[L::R + i * NU + j] * u[j];
+                cu += u[i] * r;
+            }
+            return (T(0.5) * cx + T(0.5) * cu) * dt;
         }
-#pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            T r = T(0);
-#pragma unroll
-            for (int j = 0; j < NU; ++j) r += p[L::R + i * NU + j] * u[j];
-            cu += u[i] * r;
-        }
-        return (T(0.5) * cx + T(0.5) * cu) * dt;
     }
     // l_f(x) = 0.5 dx'Q_f dx   (not scaled by dt)
     static ILQR_DEV T terminal(const T* __restrict__ p, const T* x) {
-        T dx[NX], c = T(0);
+        if constexpr (CUSTOM) {
+            return Dyn::lf(x);
+        } else {
+            T dx[NX], c = T(0);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = x[i] - p[L::XT + i];
+            for (int i = 0; i < NX; ++i) dx[i] = x[i] - p[L::XT + i];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            T r = T(0);
+            for (int i = 0; i < NX; ++i) {
+                T r = T(0);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r += p[L::QF + i * NX + j] * dx[j];
-            c += dx[i] * r;
-        }
-        return T(0.5) * c;
-    }
-    static ILQR_DEV void l_x(const T* __restrict__ p, T dt, const T* x, T* out) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            T r = T(0);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) r += p[L::QS + i * NX + j] * (x[j] - p[L::XT + j]);
-            out[i] = r * dt;
+                for (int j = 0; j < NX; ++j) r += p[L::QF + i * NX + j] * dx[j];
+                c += dx[i] * r;
+            }
+            return T(0.5) * c;
         }
     }
-    static ILQR_DEV void l_u(const T* __restrict__ p, T dt, const T* u, T* out) {
+    // gradient of the stage cost: l_x (n_x), l_u (n_u)
+    static ILQR_DEV void grad(const T* __restrict__ p, T dt, const T* x, const T* u, T* lx, T* lu) {
+        if constexpr (CUSTOM) {
+            T lxx[NX][NX], lux[NU][NX], luu[NU][NU];
+            Dyn::l_derivs(x, u, lx, lu, lxx, lux, luu);   // inlined: the unused second derivatives fold away
+        } else {
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            T r = T(0);
+            for (int i = 0; i < NX; ++i) {
+                T r = T(0);
 #pragma unroll
-            for (int j = 0; j < NU; ++j) r += p[L::RS + i * NU + j] * u[j];
-            out[i] = r * dt;
+                for (int j = 0; j < NX; ++j) r += p[L::QS + i * NX + j] * (x[j] - p[L::XT + j]);
+                lx[i] = r * dt;
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                T r = T(0);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) r += p[L::RS + i * NU + j] * u[j];
+                lu[i] = r * dt;
+            }
+        }
+    }
+    // second derivatives of the stage cost: l_xx (n_x x n_x), l_ux (n_u x n_x, system_base.py:216), l_uu
+    static ILQR_DEV void hess(const T* __restrict__ p, T dt, const T* x, const T* u, T (*lxx)[NX], T (*lux)[NX],
+                              T (*luu)[NU]) {
+        if constexpr (CUSTOM) {
+            T lx[NX], lu[NU];
+            Dyn::l_derivs(x, u, lx, lu, lxx, lux, luu);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) lxx[i][j] = p[L::QS + i * NX + j] * dt;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) lux[i][j] = T(0);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) luu[i][j] = p[L::RS + i * NU + j] * dt;
+            }
         }
     }
     static ILQR_DEV void l_f_x(const T* __restrict__ p, const T* x, T* out) {
+        if constexpr (CUSTOM) {
+            T H[NX][NX];
+            Dyn::lf_derivs(x, out, H);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-            T r = T(0);
+            for (int i = 0; i < NX; ++i) {
+                T r = T(0);
 #pragma unroll
-            for (int j = 0; j < NX; ++j) r += p[L::QFS + i * NX + j] * (x[j] - p[L::XT + j]);
-            out[i] = r;
+                for (int j = 0; j < NX; ++j) r += p[L::QFS + i * NX + j] * (x[j] - p[L::XT + j]);
+                out[i] = r;
+            }
+        }
+    }
+    static ILQR_DEV void l_f_xx(const T* __restrict__ p, const T* x, T (*H)[NX]) {
+        if constexpr (CUSTOM) {
+            T g[NX];
+            Dyn::lf_derivs(x, g, H);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) H[i][j] = p[L::QFS + i * NX + j];
         }
     }
 };

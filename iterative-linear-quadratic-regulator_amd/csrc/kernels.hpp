@@ -104,12 +104,13 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = Xp[(size_t)i * B];
     if (live && t == a.N) {
-        T g[NX];
+        T g[NX], H[NX][NX];
         Cost<T, Dyn>::l_f_x(p, x, g);
+        Cost<T, Dyn>::l_f_xx(p, x, H);
 #pragma unroll
         for (int i = 0; i < NX; ++i) a.term[(size_t)i * B + b] = g[i];
 #pragma unroll
-        for (int i = 0; i < NX * NX; ++i) a.term[(size_t)(NX + i) * B + b] = p[PL::QFS + i];
+        for (int i = 0; i < NX * NX; ++i) a.term[(size_t)(NX + i) * B + b] = H[i / NX][i % NX];
         if constexpr (!TILE16) return;
     }
     const bool point = live && t < a.N;   // this lane produces an expansion record
@@ -127,9 +128,9 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
         // 16 B per lane to consecutive addresses.
         static_assert(NX == 4 && NU == 1, "tile packing is for n_x = 4, n_u = 1");
         using V4 = typename Vec4<T>::type;
-        T gx[NX], gu1[NU];
-        Cost<T, Dyn>::l_x(p, a.dt, x, gx);
-        Cost<T, Dyn>::l_u(p, a.dt, u, gu1);
+        T gx[NX], gu1[NU], lxx[NX][NX], lux[NU][NX], luu[NU][NU];
+        Cost<T, Dyn>::grad(p, a.dt, x, u, gx, gu1);
+        Cost<T, Dyn>::hess(p, a.dt, x, u, lxx, lux, luu);
         V4 tile[12];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -138,13 +139,13 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            tile[4 + i].x = p[PL::QS + 4 * i + 0] * a.dt; tile[4 + i].y = p[PL::QS + 4 * i + 1] * a.dt;
-            tile[4 + i].z = p[PL::QS + 4 * i + 2] * a.dt; tile[4 + i].w = p[PL::QS + 4 * i + 3] * a.dt;
+            tile[4 + i].x = lxx[i][0]; tile[4 + i].y = lxx[i][1];
+            tile[4 + i].z = lxx[i][2]; tile[4 + i].w = lxx[i][3];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tile[8 + j].x = fu[j][0]; tile[8 + j].y = gx[j]; tile[8 + j].z = T(0);
-            tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? p[PL::RS] * a.dt : T(0));
+            tile[8 + j].x = fu[j][0]; tile[8 + j].y = gx[j]; tile[8 + j].z = lux[0][j];
+            tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
         }
         // passes over groups of whole tiles (so every pass writes one contiguous run of full cache lines):
         // 64 tiles at once in f32, 2 x 32 tiles in f64; ~13 KB of LDS per wave either way
@@ -193,19 +194,19 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     for (int i = 0; i < NX; ++i)
 #pragma unroll
         for (int j = 0; j < NU; ++j) out[(size_t)(e++) * B] = fu[i][j];
-    T g[NX], gu[NU];
-    Cost<T, Dyn>::l_x(p, a.dt, x, g);
-    Cost<T, Dyn>::l_u(p, a.dt, u, gu);
+    T g[NX], gu[NU], lxx[NX][NX], lux[NU][NX], luu[NU][NU];
+    Cost<T, Dyn>::grad(p, a.dt, x, u, g, gu);
+    Cost<T, Dyn>::hess(p, a.dt, x, u, lxx, lux, luu);
 #pragma unroll
     for (int i = 0; i < NX; ++i) out[(size_t)(e++) * B] = g[i];
 #pragma unroll
     for (int i = 0; i < NU; ++i) out[(size_t)(e++) * B] = gu[i];
 #pragma unroll
-    for (int i = 0; i < NX * NX; ++i) out[(size_t)(e++) * B] = p[PL::QS + i] * a.dt;
+    for (int i = 0; i < NX * NX; ++i) out[(size_t)(e++) * B] = lxx[i / NX][i % NX];
 #pragma unroll
-    for (int i = 0; i < NU * NX; ++i) out[(size_t)(e++) * B] = T(0);
+    for (int i = 0; i < NU * NX; ++i) out[(size_t)(e++) * B] = lux[i / NX][i % NX];
 #pragma unroll
-    for (int i = 0; i < NU * NU; ++i) out[(size_t)(e++) * B] = p[PL::RS + i] * a.dt;
+    for (int i = 0; i < NU * NU; ++i) out[(size_t)(e++) * B] = luu[i / NU][i % NU];
 }
 
 // ---------------------------------------------------------------------------
@@ -830,27 +831,29 @@ __global__ void __launch_bounds__(64) eval_points_kernel(EvalArgs<T> a) {
         for (int r = 0; r < NX; ++r) a.f[(size_t)i * NX + r] = xn[r];
     }
     if (a.l) a.l[i] = Cost<T, Dyn>::stage(p, a.dt, x, u);
-    if (a.l_x) {
-        T g[NX];
-        Cost<T, Dyn>::l_x(p, a.dt, x, g);
+    if (a.l_x || a.l_u) {
+        T g[NX], gu[NU];
+        Cost<T, Dyn>::grad(p, a.dt, x, u, g, gu);
 #pragma unroll
-        for (int r = 0; r < NX; ++r) a.l_x[(size_t)i * NX + r] = g[r];
+        for (int r = 0; r < NX; ++r)
+            if (a.l_x) a.l_x[(size_t)i * NX + r] = g[r];
+#pragma unroll
+        for (int r = 0; r < NU; ++r)
+            if (a.l_u) a.l_u[(size_t)i * NU + r] = gu[r];
     }
-    if (a.l_u) {
-        T g[NU];
-        Cost<T, Dyn>::l_u(p, a.dt, u, g);
+    if (a.l_xx || a.l_ux || a.l_uu) {
+        T lxx[NX][NX], lux[NU][NX], luu[NU][NU];
+        Cost<T, Dyn>::hess(p, a.dt, x, u, lxx, lux, luu);
 #pragma unroll
-        for (int r = 0; r < NU; ++r) a.l_u[(size_t)i * NU + r] = g[r];
+        for (int r = 0; r < NX * NX; ++r)
+            if (a.l_xx) a.l_xx[(size_t)i * NX * NX + r] = lxx[r / NX][r % NX];
+#pragma unroll
+        for (int r = 0; r < NU * NX; ++r)
+            if (a.l_ux) a.l_ux[(size_t)i * NU * NX + r] = lux[r / NX][r % NX];
+#pragma unroll
+        for (int r = 0; r < NU * NU; ++r)
+            if (a.l_uu) a.l_uu[(size_t)i * NU * NU + r] = luu[r / NU][r % NU];
     }
-    if (a.l_xx)
-#pragma unroll
-        for (int r = 0; r < NX * NX; ++r) a.l_xx[(size_t)i * NX * NX + r] = p[PL::QS + r] * a.dt;
-    if (a.l_ux)
-#pragma unroll
-        for (int r = 0; r < NU * NX; ++r) a.l_ux[(size_t)i * NU * NX + r] = T(0);
-    if (a.l_uu)
-#pragma unroll
-        for (int r = 0; r < NU * NU; ++r) a.l_uu[(size_t)i * NU * NU + r] = p[PL::RS + r] * a.dt;
     if (a.l_f) a.l_f[i] = Cost<T, Dyn>::terminal(p, x);
     if (a.l_f_x) {
         T g[NX];
@@ -858,9 +861,12 @@ __global__ void __launch_bounds__(64) eval_points_kernel(EvalArgs<T> a) {
 #pragma unroll
         for (int r = 0; r < NX; ++r) a.l_f_x[(size_t)i * NX + r] = g[r];
     }
-    if (a.l_f_xx)
+    if (a.l_f_xx) {
+        T H[NX][NX];
+        Cost<T, Dyn>::l_f_xx(p, x, H);
 #pragma unroll
-        for (int r = 0; r < NX * NX; ++r) a.l_f_xx[(size_t)i * NX * NX + r] = p[PL::QFS + r];
+        for (int r = 0; r < NX * NX; ++r) a.l_f_xx[(size_t)i * NX * NX + r] = H[r / NX][r % NX];
+    }
 }
 
 // ---------------------------------------------------------------------------

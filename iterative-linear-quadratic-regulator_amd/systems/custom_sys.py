@@ -11,8 +11,9 @@ kernel templates the built-in systems use (integrators and their chain-rule Jaco
 n_x = 4 / n_u = 1 DPP backward sweep, the ring rollout, the solver).  The resulting plugin is
 loaded through ``ilqr_create_custom`` (include/ilqr_hip.h).
 
-Scope (this round): n_x <= 6, n_u <= n_x, and the quadratic cost every reference system uses
-(pendulum_sys.py:77-98) given as ``x_target, Q, R, Q_f``; a user ``_l_fcn`` is not traced yet.
+Scope: n_x <= 6, n_u <= n_x.  The cost is either the quadratic form every reference system uses
+(pendulum_sys.py:77-98, given as ``x_target, Q, R, Q_f``) or the user's own ``_l_fcn`` / ``_l_f_fcn``
+(system_base.py:262-275), traced and differentiated twice like the dynamics.
 There is no interpreter fallback: without hipcc the plugin cannot be built and construction of
 a handle raises.
 """
@@ -77,19 +78,10 @@ def sp_half():
     return sp.Rational(1, 2)
 
 
-def generate_dyn_bodies(f_cont, n_x, n_u):
-    """Trace ``f_cont(x, u)`` with sympy symbols; returns (f_body, fjac_body) C++ statement blocks."""
+def _trace_symbols(n_x, n_u):
     import sympy as sp
     xs = sp.symbols(f"x_0:{n_x}", real=True)
     us = sp.symbols(f"u_0:{n_u}", real=True)
-    out = f_cont(list(xs), list(us))
-    out = [sp.sympify(e) for e in (out.tolist() if hasattr(out, "tolist") else list(out))]
-    out = [e[0] if isinstance(e, (list, tuple)) else e for e in out]
-    if len(out) != n_x:
-        raise ValueError(f"_f_cont_fcn returned {len(out)} components, expected n_x = {n_x}")
-    free = set().union(*[e.free_symbols for e in out]) - set(xs) - set(us)
-    if free:
-        raise ValueError(f"_f_cont_fcn has free symbols other than x, u: {sorted(map(str, free))}")
     names = {**{s: f"x[{i}]" for i, s in enumerate(xs)}, **{s: f"u[{i}]" for i, s in enumerate(us)}}
     pr = _printer(n_x, n_u)
     pr._print_Symbol = lambda s: names.get(s, s.name)  # cse temporaries keep their own names
@@ -100,6 +92,24 @@ def generate_dyn_bodies(f_cont, n_x, n_u):
         lines += [f"        {name} = {pr.doprint(e)};" for (name, _), e in zip(targets, red)]
         return "\n".join(lines)
 
+    def check_free(exprs, what):
+        free = set().union(*[e.free_symbols for e in exprs]) - set(xs) - set(us)
+        if free:
+            raise ValueError(f"{what} has free symbols other than x, u: {sorted(map(str, free))}")
+
+    return xs, us, block, check_free
+
+
+def generate_dyn_bodies(f_cont, n_x, n_u):
+    """Trace ``f_cont(x, u)`` with sympy symbols; returns (f_body, fjac_body) C++ statement blocks."""
+    import sympy as sp
+    xs, us, block, check_free = _trace_symbols(n_x, n_u)
+    out = f_cont(list(xs), list(us))
+    out = [sp.sympify(e) for e in (out.tolist() if hasattr(out, "tolist") else list(out))]
+    out = [e[0] if isinstance(e, (list, tuple)) else e for e in out]
+    if len(out) != n_x:
+        raise ValueError(f"_f_cont_fcn returned {len(out)} components, expected n_x = {n_x}")
+    check_free(out, "_f_cont_fcn")
     f_targets = [(f"xd[{i}]", e) for i, e in enumerate(out)]
     jac = list(f_targets)
     jac += [(f"Jx[{i}][{j}]", sp.diff(out[i], xs[j])) for i in range(n_x) for j in range(n_x)]
@@ -107,10 +117,37 @@ def generate_dyn_bodies(f_cont, n_x, n_u):
     return block(f_targets), block(jac)
 
 
-def render_plugin_source(f_cont, n_x, n_u, dtype):
+def generate_cost_bodies(l_fcn, l_f_fcn, n_x, n_u):
+    """Trace the user's stage and terminal cost; returns the four bodies (l, l derivatives, l_f, l_f derivatives).
+    Derivative layout follows the reference (system_base.py:212-219): l_ux = d/dx (dl/du), shape (n_u, n_x)."""
+    import sympy as sp
+    xs, us, block, check_free = _trace_symbols(n_x, n_u)
+    l = sp.sympify(l_fcn(list(xs), list(us)))
+    lf = sp.sympify(l_f_fcn(list(xs)))
+    check_free([l], "_l_fcn")
+    check_free([lf], "_l_f_fcn")
+    if lf.free_symbols & set(us):
+        raise ValueError("_l_f_fcn must depend on x only")
+    d = [(f"lx[{i}]", sp.diff(l, xs[i])) for i in range(n_x)] + [(f"lu[{j}]", sp.diff(l, us[j])) for j in range(n_u)]
+    d += [(f"lxx[{i}][{j}]", sp.diff(l, xs[i], xs[j])) for i in range(n_x) for j in range(n_x)]
+    d += [(f"lux[{j}][{i}]", sp.diff(l, us[j], xs[i])) for j in range(n_u) for i in range(n_x)]
+    d += [(f"luu[{i}][{j}]", sp.diff(l, us[i], us[j])) for i in range(n_u) for j in range(n_u)]
+    df = [(f"g[{i}]", sp.diff(lf, xs[i])) for i in range(n_x)]
+    df += [(f"H[{i}][{j}]", sp.diff(lf, xs[i], xs[j])) for i in range(n_x) for j in range(n_x)]
+    return block([("out", l)]), block(d), block([("out", lf)]), block(df)
+
+
+def render_plugin_source(f_cont, n_x, n_u, dtype, l_fcn=None, l_f_fcn=None):
     f_body, fjac_body = generate_dyn_bodies(f_cont, n_x, n_u)
+    if l_fcn is not None:
+        cost = generate_cost_bodies(l_fcn, l_f_fcn, n_x, n_u)
+    else:
+        cost = ("        out = T(0);", "", "        out = T(0);", "")
     src = open(TEMPLATE).read()
     for key, val in (("@NX@", str(n_x)), ("@NU@", str(n_u)), ("@F_BODY@", f_body), ("@FJAC_BODY@", fjac_body),
+                     ("@CUSTOM_COST@", "true" if l_fcn is not None else "false"),
+                     ("@L_BODY@", cost[0]), ("@L_DERIVS_BODY@", cost[1]), ("@LF_BODY@", cost[2]),
+                     ("@LF_DERIVS_BODY@", cost[3]),
                      ("@DTYPE@", "float" if np.dtype(dtype) == np.float32 else "double")):
         src = src.replace(key, val)
     return src
@@ -175,30 +212,60 @@ class SymbolicSystem(System):
     ``_f_cont_fcn(self, x, u) -> sequence of n_x expressions`` with sympy math.  All twelve public
     callables (``f_fcn`` ... ``l_f_xx_fcn``), ``iLQR(system, ...)``, ``solve`` and the MPC loop then work
     as for the built-in systems.
+
+    Cost: either the quadratic form every reference system uses (give ``x_target, Q, R, Q_f``), or -- the full
+    reference contract (system_base.py:262-275) -- override BOTH ``_l_fcn(self, x, u)`` and ``_l_f_fcn(self, x)``
+    with sympy expressions; they are differentiated twice symbolically and compiled like the dynamics
+    (``_l_fcn`` returns the stage cost exactly as written: multiply by ``self.dt`` yourself if you want the
+    reference systems' convention, pendulum_sys.py:86).
     """
 
     SYSTEM_ID = _lib.SYS_CUSTOM
 
-    def __init__(self, n_x, n_u, dt, x_target, Q, R, Q_f, use_jit=True, integrator="rk4", dtype=np.float64):
+    def __init__(self, n_x, n_u, dt, x_target=None, Q=None, R=None, Q_f=None, use_jit=True, integrator="rk4",
+                 dtype=np.float64):
         super().__init__(n_x, n_u, dt, use_jit=use_jit, integrator=integrator, dtype=dtype)
         if not (1 <= self.n_x <= 6 and 1 <= self.n_u <= self.n_x):
             raise ValueError("user-defined systems support 1 <= n_u <= n_x <= 6")
+        own_l = type(self)._l_fcn is not SymbolicSystem._l_fcn
+        own_lf = type(self)._l_f_fcn is not SymbolicSystem._l_f_fcn
+        if own_l != own_lf:
+            raise ValueError("override both _l_fcn and _l_f_fcn, or neither (quadratic cost)")
+        self.custom_cost = own_l
+        if self.custom_cost:
+            n, m = self.n_x, self.n_u   # the quadratic block is unused: neutral placeholders
+            x_target = np.zeros(n) if x_target is None else x_target
+            Q, R, Q_f = (np.zeros((k, k)) if a is None else a for a, k in ((Q, n), (R, m), (Q_f, n)))
+        elif any(a is None for a in (x_target, Q, R, Q_f)):
+            raise ValueError("give x_target, Q, R, Q_f (quadratic cost) or override _l_fcn and _l_f_fcn")
         self._set_cost(x_target, Q, R, Q_f)
         self._plugins = {}
 
     def _f_cont_fcn(self, x, u):
         raise NotImplementedError("subclasses implement the continuous dynamics x_dot = f_c(x, u) (system_base.py:255)")
 
+    def _l_fcn(self, x, u):
+        raise NotImplementedError
+
+    def _l_f_fcn(self, x):
+        raise NotImplementedError
+
     def _system_params(self):
         return []  # the constants are part of the generated code
 
+    def _bodies(self):
+        b = generate_dyn_bodies(self._f_cont_fcn, self.n_x, self.n_u)
+        if self.custom_cost:
+            b += generate_cost_bodies(self._l_fcn, self._l_f_fcn, self.n_x, self.n_u)
+        return b
+
     def same_dynamics(self, other):
-        return (super().same_dynamics(other) and
-                generate_dyn_bodies(self._f_cont_fcn, self.n_x, self.n_u) ==
-                generate_dyn_bodies(other._f_cont_fcn, other.n_x, other.n_u))
+        return super().same_dynamics(other) and self._bodies() == other._bodies()
 
     def plugin_source(self, dtype=None):
-        return render_plugin_source(self._f_cont_fcn, self.n_x, self.n_u, self.dtype if dtype is None else dtype)
+        return render_plugin_source(self._f_cont_fcn, self.n_x, self.n_u, self.dtype if dtype is None else dtype,
+                                    self._l_fcn if self.custom_cost else None,
+                                    self._l_f_fcn if self.custom_cost else None)
 
     def plugin_path(self, dtype=None, verbose=False):
         dt = np.dtype(self.dtype if dtype is None else dtype)

@@ -86,8 +86,49 @@ class PlanarQuadrotor(SymbolicSystem):
                 self.arm * (u[1] - u[0]) / self.inertia]
 
 
+class SwingUpCartPole(CartPole):
+    """Cart-pole with a non-quadratic user cost (the full subclass contract, system_base.py:255-275): pseudo-Huber
+    angle error, a quartic control term, and a control/velocity cross term so that l_ux is not zero."""
+
+    def __init__(self, dt, **kw):
+        SymbolicSystem.__init__(self, 4, 1, dt, **kw)
+        self.m_cart, self.m_pole, self.length, self.g = 1.0, 0.2, 0.5, 9.81
+
+    def _l_fcn(self, x, u):
+        p, th, pd, thd = x
+        huber = sp.sqrt((th - sp.pi) ** 2 + 0.25)
+        return self.dt * (0.5 * p ** 2 + 2.0 * huber + 0.05 * pd ** 2 + 0.05 * thd ** 2
+                          + 0.01 * u[0] ** 2 + 0.001 * u[0] ** 4 + 0.004 * u[0] * pd)
+
+    def _l_f_fcn(self, x):
+        p, th, pd, thd = x
+        return 50.0 * p ** 2 + 40.0 * (th - sp.pi) ** 2 + 20.0 * sp.sqrt((th - sp.pi) ** 2 + 0.25) + 5.0 * pd ** 2 \
+            + 5.0 * thd ** 2
+
+
+class ObstacleUnicycle(Unicycle):
+    """Unicycle steering to a goal past a soft (Gaussian) obstacle; n_u = 2 with coupled controls.  The bump is
+    kept weaker than the quadratic terms so the stage cost stays convex (plain iLQR, like the reference, has no
+    safeguard against indefinite Hessians beyond the optional mu)."""
+
+    goal = (1.0, 1.0)
+    obstacle = (0.5, 0.4, 0.3, 0.03)   # centre x, y, width, height
+
+    def __init__(self, dt, **kw):
+        SymbolicSystem.__init__(self, 3, 2, dt, **kw)
+
+    def _l_fcn(self, x, u):
+        ox, oy, w, a = self.obstacle
+        bump = a * sp.exp(-((x[0] - ox) ** 2 + (x[1] - oy) ** 2) / (2 * w ** 2))
+        return self.dt * (0.5 * (x[0] - self.goal[0]) ** 2 + 0.5 * (x[1] - self.goal[1]) ** 2 + 0.05 * x[2] ** 2 + bump
+                          + 0.1 * u[0] ** 2 + 0.1 * u[1] ** 2 + 0.05 * u[0] * u[1] + 0.02 * u[1] * x[2])
+
+    def _l_f_fcn(self, x):
+        return 50.0 * (x[0] - self.goal[0]) ** 2 + 50.0 * (x[1] - self.goal[1]) ** 2 + 2.0 * (x[2] - 0.5) ** 2
+
+
 def example_problems(dtype=np.float64, integrator="rk4"):
-    """name -> (system, N, x_0, initial control scale): the cases the tests and build() pre-compile."""
+    """name -> (system, N, x_0): the cases the tests and build() pre-compile."""
     kw = dict(dtype=dtype, integrator=integrator)
     pi = np.pi
     return {
@@ -102,4 +143,24 @@ def example_problems(dtype=np.float64, integrator="rk4"):
         "quadrotor": (PlanarQuadrotor(0.02, [1.0, 1.0, 0, 0, 0, 0], np.diag([1.0, 1.0, 1.0, 0.1, 0.1, 0.1]),
                                       np.diag([0.1, 0.1]), np.diag([100.0, 100.0, 10.0, 10.0, 10.0, 1.0]), **kw),
                       50, np.array([0.0, 0.0, 0.0, 0, 0, 0])),
+        "swingup_cartpole": (SwingUpCartPole(0.02, **kw), 80, np.array([0.0, 0.3, 0, 0])),
+        "obstacle_unicycle": (ObstacleUnicycle(0.05, **kw), 60, np.array([0.0, 0.0, 0.3])),
     }
+
+
+def bench_cases():
+    """User systems at the north-star shape (B = 4096, N = 200, n = 4, m = 1) for tools/bench_configs.py: the symbolic
+    restatement of the reference's UA double pendulum (same parameters as problems.ua_double_pendulum) and the
+    cart-pole with its non-quadratic user cost.  name -> (system, N, B, x_0 centre)."""
+    from .. import problems
+    p = problems.ua_double_pendulum(N=200)
+    d, c = p["dynamics"], p["cost"]
+    phys = {k: d[k] for k in ("g", "m1", "m2", "l1", "l2", "d1", "d2") if k in d}
+    out = {}
+    for tag, dt in (("f32", np.float32), ("f64", np.float64)):
+        sym = SymbolicUADoublePendulum(d["dt"], c["x_target"], c["Q"], c["R"], c["Q_f"], integrator=d["integrator"],
+                                       dtype=dt, **phys)
+        out[f"user {tag}: symbolic UA double pendulum rk4"] = (sym, 200, 4096, np.asarray(p["x0"], dtype=np.float64))
+    out["user float32: cart-pole + non-quadratic cost rk4"] = (SwingUpCartPole(0.02, dtype=np.float32), 200, 4096,
+                                                              np.array([0.0, 0.3, 0.0, 0.0]))
+    return out

@@ -14,9 +14,20 @@ from .systems import OracleSystem
 
 
 class CallableOracle(OracleSystem):
-    def __init__(self, f_cont, n_x, n_u, dt, x_target, Q, R, Q_f, integrator="rk4", dtype=np.float64):
-        super().__init__(n_x, n_u, dt, x_target, Q, R, Q_f, integrator=integrator, dtype=dtype)
+    """``f_cont`` (and optionally the costs ``l(x, u)``, ``l_f(x)``) as plain NumPy callables.
+
+    First derivatives by the complex step; second derivatives by a complex step in one argument and a central
+    difference (step 1e-5, error O(1e-10) for smooth costs) in the other, symmetrised where the exact matrix is.
+    """
+
+    def __init__(self, f_cont, n_x, n_u, dt, x_target=None, Q=None, R=None, Q_f=None, integrator="rk4",
+                 dtype=np.float64, l=None, l_f=None):
+        z = lambda a, k: np.zeros((k, k)) if a is None else a
+        super().__init__(n_x, n_u, dt, np.zeros(n_x) if x_target is None else x_target, z(Q, n_x), z(R, n_u),
+                         z(Q_f, n_x), integrator=integrator, dtype=dtype)
         self._fc = f_cont
+        self._l, self._lf = l, l_f
+        assert (l is None) == (l_f is None)
 
     def f_cont(self, x, u):
         return np.asarray(self._fc(x, u), dtype=self.dtype)
@@ -38,6 +49,84 @@ class CallableOracle(OracleSystem):
 
     def f_cont_u(self, x, u):
         return self._cstep(x, u, 1)
+
+    # ---- user costs ----------------------------------------------------------------------------
+    @staticmethod
+    def _grad(fun, z):
+        """complex-step gradient of scalar fun at real-or-complex z (complex z: used by _hess)."""
+        g = np.zeros(len(z), dtype=np.complex128)
+        for i in range(len(z)):
+            zc = np.asarray(z, dtype=np.complex128).copy()
+            zc[i] += 1e-30j
+            g[i] = np.imag(fun(zc)) / 1e-30
+        return g
+
+    @staticmethod
+    def _hess(fun, z, d=1e-5):
+        """H[i, j] = d/dz_j (d fun / dz_i): complex step in i, central difference in j."""
+        n = len(z)
+        H = np.zeros((n, n))
+        for j in range(n):
+            zp, zm = np.asarray(z, dtype=np.float64).copy(), np.asarray(z, dtype=np.float64).copy()
+            zp[j] += d
+            zm[j] -= d
+            gp, gm = np.zeros(n), np.zeros(n)
+            for i in range(n):
+                a, b = zp.astype(np.complex128), zm.astype(np.complex128)
+                a[i] += 1e-30j
+                b[i] += 1e-30j
+                gp[i], gm[i] = np.imag(fun(a)) / 1e-30, np.imag(fun(b)) / 1e-30
+            H[:, j] = (gp - gm) / (2 * d)
+        return H
+
+    def _joint(self):
+        n = self.n_x
+        return lambda z: self._l(z[:n], z[n:])
+
+    def l(self, x, u):
+        if self._l is None:
+            return super().l(x, u)
+        return self.dtype.type(self._l(np.asarray(x, np.float64), np.asarray(u, np.float64)))
+
+    def _lz(self, x, u):
+        return np.real(self._grad(self._joint(), np.concatenate([x, u]))).astype(self.dtype)
+
+    def _lzz(self, x, u):
+        H = self._hess(self._joint(), np.concatenate([x, u]))
+        return (0.5 * (H + H.T)).astype(self.dtype)
+
+    def l_x(self, x, u):
+        return super().l_x(x, u) if self._l is None else self._lz(x, u)[:self.n_x]
+
+    def l_u(self, x, u):
+        return super().l_u(x, u) if self._l is None else self._lz(x, u)[self.n_x:]
+
+    def l_xx(self, x, u):
+        return super().l_xx(x, u) if self._l is None else self._lzz(x, u)[:self.n_x, :self.n_x]
+
+    def l_uu(self, x, u):
+        return super().l_uu(x, u) if self._l is None else self._lzz(x, u)[self.n_x:, self.n_x:]
+
+    def l_ux(self, x, u):
+        return super().l_ux(x, u) if self._l is None else self._lzz(x, u)[self.n_x:, :self.n_x]
+
+    def l_f(self, x):
+        return super().l_f(x) if self._lf is None else self.dtype.type(self._lf(np.asarray(x, np.float64)))
+
+    def l_f_x(self, x):
+        if self._lf is None:
+            return super().l_f_x(x)
+        return np.real(self._grad(self._lf, np.asarray(x, np.float64))).astype(self.dtype)
+
+    def l_f_xx(self, x):
+        if self._lf is None:
+            return super().l_f_xx(x)
+        H = self._hess(self._lf, np.asarray(x, np.float64))
+        return (0.5 * (H + H.T)).astype(self.dtype)
+
+    # the reference's public names (system_base.py:223-251) must see the overrides above
+    l_fcn, l_x_fcn, l_u_fcn, l_xx_fcn, l_uu_fcn, l_ux_fcn = l, l_x, l_u, l_xx, l_uu, l_ux
+    l_f_fcn, l_f_x_fcn, l_f_xx_fcn = l_f, l_f_x, l_f_xx
 
 
 # ---- NumPy twins of iterative-linear-quadratic-regulator_amd/systems/examples.py (written independently) ----
@@ -70,6 +159,30 @@ def quadrotor_fc(mass=0.5, inertia=0.01, arm=0.2, g=9.81):
     return fc
 
 
+def swingup_costs(dt):
+    def l(x, u):
+        e = x[1] - np.pi
+        return dt * (0.5 * x[0] ** 2 + 2.0 * np.sqrt(e * e + 0.25) + 0.05 * x[2] ** 2 + 0.05 * x[3] ** 2
+                     + 0.01 * u[0] ** 2 + 0.001 * u[0] ** 4 + 0.004 * u[0] * x[2])
+
+    def lf(x):
+        e = x[1] - np.pi
+        return 50.0 * x[0] ** 2 + 40.0 * e * e + 20.0 * np.sqrt(e * e + 0.25) + 5.0 * x[2] ** 2 + 5.0 * x[3] ** 2
+    return l, lf
+
+
+def obstacle_costs(dt, goal=(1.0, 1.0), obstacle=(0.5, 0.4, 0.3, 0.03)):
+    ox, oy, w, a = obstacle
+
+    def l(x, u):
+        bump = a * np.exp(-((x[0] - ox) ** 2 + (x[1] - oy) ** 2) / (2 * w ** 2))
+        return dt * (0.5 * (x[0] - goal[0]) ** 2 + 0.5 * (x[1] - goal[1]) ** 2 + 0.05 * x[2] ** 2 + bump
+                     + 0.1 * u[0] ** 2 + 0.1 * u[1] ** 2 + 0.05 * u[0] * u[1] + 0.02 * u[1] * x[2])
+
+    lf = lambda x: 50.0 * (x[0] - goal[0]) ** 2 + 50.0 * (x[1] - goal[1]) ** 2 + 2.0 * (x[2] - 0.5) ** 2
+    return l, lf
+
+
 def oracle_for_example(name, system, dtype=np.float64, integrator=None):
     """Oracle twin of one of the example user systems (sym_ua is checked against the built-in
     UADoublePendulumOracle instead: same physics, independently written)."""
@@ -79,8 +192,13 @@ def oracle_for_example(name, system, dtype=np.float64, integrator=None):
     if name == "sym_ua":
         return UADoublePendulumOracle(g=system.g, m1=system.m1, m2=system.m2, l1=system.l1, l2=system.l2,
                                       d1=system.d1, d2=system.d2, theta1=system.theta1, theta2=system.theta2, **common)
+    cart = lambda: cartpole_fc(system.m_cart, system.m_pole, system.length, system.g)
     fc = {"sym_pendulum": lambda: pendulum_fc(system.g, system.l, system.d),
-          "cartpole": lambda: cartpole_fc(system.m_cart, system.m_pole, system.length, system.g),
-          "unicycle": unicycle_fc,
+          "cartpole": cart, "swingup_cartpole": cart,
+          "unicycle": unicycle_fc, "obstacle_unicycle": unicycle_fc,
           "quadrotor": lambda: quadrotor_fc(system.mass, system.inertia, system.arm, system.g)}[name]()
+    if name == "swingup_cartpole":
+        common["l"], common["l_f"] = swingup_costs(system.dt)
+    if name == "obstacle_unicycle":
+        common["l"], common["l_f"] = obstacle_costs(system.dt, system.goal, system.obstacle)
     return CallableOracle(fc, system.n_x, system.n_u, **common)

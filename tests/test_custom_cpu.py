@@ -13,7 +13,7 @@ from ilqr_amd.systems.custom_sys import generate_dyn_bodies
 from ilqr_amd.systems.examples import example_problems
 from oracle.custom import oracle_for_example
 
-NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "quadrotor"]
+NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "quadrotor", "swingup_cartpole", "obstacle_unicycle"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -31,6 +31,32 @@ def test_oracle_twin_matches_symbolic_statement(name):
         np.testing.assert_allclose(np.ravel(F(x, u)), o.f_cont(x, u), rtol=1e-12, atol=1e-13)
         np.testing.assert_allclose(JX(x, u), o.f_cont_x(x, u), rtol=1e-11, atol=1e-12)
         np.testing.assert_allclose(JU(x, u), o.f_cont_u(x, u), rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["swingup_cartpole", "obstacle_unicycle"])
+def test_oracle_cost_derivatives_match_symbolic_statement(name):
+    """User costs: the oracle's complex-step / mixed finite-difference derivatives against sympy's exact ones."""
+    s, _, _ = example_problems()[name]
+    assert s.custom_cost
+    o = oracle_for_example(name, s)
+    n = s.n_x
+    xs, us = sp.symbols(f"x0:{s.n_x}"), sp.symbols(f"u0:{s.n_u}")
+    l, lf = s._l_fcn(list(xs), list(us)), s._l_f_fcn(list(xs))
+    z = list(xs) + list(us)
+    L, G, H = (sp.lambdify([xs, us], e, "numpy") for e in (l, sp.Matrix([l]).jacobian(z), sp.hessian(l, z)))
+    LF, GF, HF = (sp.lambdify([xs], e, "numpy") for e in (lf, sp.Matrix([lf]).jacobian(xs), sp.hessian(lf, xs)))
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        x, u = rng.standard_normal(s.n_x), rng.standard_normal(s.n_u)
+        np.testing.assert_allclose(L(x, u), o.l(x, u), rtol=1e-13)
+        np.testing.assert_allclose(np.ravel(G(x, u))[:n], o.l_x(x, u), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(np.ravel(G(x, u))[n:], o.l_u(x, u), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(H(x, u)[:n, :n], o.l_xx(x, u), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(H(x, u)[n:, :n], o.l_ux(x, u), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(H(x, u)[n:, n:], o.l_uu(x, u), rtol=1e-7, atol=1e-9)
+        np.testing.assert_allclose(LF(x), o.l_f(x), rtol=1e-13)
+        np.testing.assert_allclose(np.ravel(GF(x)), o.l_f_x(x), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(HF(x), o.l_f_xx(x), rtol=1e-7, atol=1e-8)
 
 
 def test_generated_code_is_typed_and_complete():
@@ -57,9 +83,20 @@ def test_bad_user_dynamics_are_rejected():
         def _f_cont_fcn(self, x, u):
             return [x[1], sp.Symbol("k") * u[0]]  # unbound constant
 
+    class HalfCost(SymbolicSystem):
+        def _f_cont_fcn(self, x, u):
+            return [x[1], u[0]]
+
+        def _l_fcn(self, x, u):                   # _l_f_fcn missing
+            return x[0] ** 2 + u[0] ** 2
+
     for cls in (Wrong, Free):
         with pytest.raises(ValueError):
             cls(2, 1, 0.01, [0, 0], np.eye(2), [[1.0]], np.eye(2)).plugin_source()
+    with pytest.raises(ValueError):
+        HalfCost(2, 1, 0.01)
+    with pytest.raises(ValueError):               # neither a quadratic cost nor user costs
+        Wrong(2, 1, 0.01)
     with pytest.raises(ValueError):
         SymbolicSystem(7, 1, 0.01, np.zeros(7), np.eye(7), [[1.0]], np.eye(7))
     with pytest.raises(ValueError):  # same message as the reference's System (system_base.py:198)

@@ -11,7 +11,7 @@ from oracle import backward_pass, forward_pass, iLQROracle, mpc_closed_loop
 from oracle.custom import oracle_for_example
 
 pytestmark = pytest.mark.gpu
-NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "quadrotor"]
+NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "quadrotor", "swingup_cartpole", "obstacle_unicycle"]
 RTOL = 1e-5
 
 
@@ -31,10 +31,11 @@ def test_custom_system_callables(name, integrator):
     for _ in range(4):
         x, u = rng.standard_normal(s.n_x) * 0.8, rng.standard_normal(s.n_u) * 1.5
         for fn in ("f_fcn", "f_x_fcn", "f_u_fcn", "l_fcn", "l_x_fcn", "l_u_fcn", "l_xx_fcn", "l_uu_fcn", "l_ux_fcn"):
-            np.testing.assert_allclose(getattr(s, fn)(x, u), getattr(o, fn)(x, u), rtol=1e-8, atol=1e-10,
+            # (the oracle's second derivatives of a user cost carry its finite-difference error, ~1e-9)
+            np.testing.assert_allclose(getattr(s, fn)(x, u), getattr(o, fn)(x, u), rtol=1e-7, atol=1e-9,
                                        err_msg=f"{name} {integrator} {fn}")
         for fn in ("l_f_fcn", "l_f_x_fcn", "l_f_xx_fcn"):
-            np.testing.assert_allclose(getattr(s, fn)(x), getattr(o, fn)(x), rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(getattr(s, fn)(x), getattr(o, fn)(x), rtol=1e-7, atol=1e-8)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -62,7 +63,8 @@ def test_custom_backward_and_forward_pass(name, dtype):
             _close(Xn[b], Xo, 1e-6 if dtype == np.float64 else 1e-4, f"{name} X")
 
 
-@pytest.mark.parametrize("name,maxiter", [("sym_pendulum", 15), ("cartpole", 10), ("unicycle", 12), ("quadrotor", 8)])
+@pytest.mark.parametrize("name,maxiter", [("sym_pendulum", 15), ("cartpole", 10), ("unicycle", 12), ("quadrotor", 8),
+                                          ("swingup_cartpole", 10), ("obstacle_unicycle", 10)])
 def test_custom_full_solve(name, maxiter):
     """optimize_trajectory on a user system: same accepted alphas / iteration counts / status as the oracle."""
     s, N, x0 = example_problems()[name]

@@ -30,3 +30,13 @@ for dt in (np.float32, np.float64):
     x0, U0 = problems.lq_batch(128, 16, 8, 500)
     w, ph = time_iters(ilqr_amd.make_system(p["dynamics"], p["cost"], dt), x0, U0, 500)
     print(f"c5-shard {name}: LQ n=16 m=8 N=500 B=128: {w*1e6:.0f} us/iteration = {128/w/1e3:.1f} k it/s {ph}")
+
+# user-defined systems (generated plugins, systems/custom_sys.py) at the c3 shape
+from ilqr_amd.systems.examples import bench_cases
+for name, (sysm, N, B, x0c) in bench_cases().items():
+    rng = np.random.default_rng(0)
+    dt = sysm.dtype
+    x0 = (x0c[None, :] + 0.05 * rng.standard_normal((B, sysm.n_x))).astype(dt)
+    U0 = (0.1 * rng.standard_normal((B, sysm.n_u, N))).astype(dt)
+    w, ph = time_iters(sysm, x0, U0, N)
+    print(f"{name} N={N} B={B}: {w*1e6:.0f} us/iteration = {B/w/1e6:.2f} M it/s {ph}")
