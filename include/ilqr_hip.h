@@ -204,6 +204,13 @@ int ilqr_solve(ilqr_handle h, int32_t* iters_out, void* cost_out);
  *      they do not touch the solver state ------------------------------------ */
 /* iLQR.backward_pass(X, U) -> (U_ff, K)   (iLQR_class.py:68, 122-161) */
 int ilqr_backward_pass(ilqr_handle h, const void* X, const void* U, void* U_ff_out, void* K_out);
+/* The sweep of iLQR.backward_pass alone (iLQR_class.py:136-151) on an expansion the CALLER computed -- its own
+ * autodiff, an identified model, time-varying LQ data -- instead of _get_all_derivatives_for_backward_pass
+ * (iLQR_class.py:318-331).  lin [B][N][E]: per step f_x (n*n, row-major), f_u (n*m), l_x (n), l_u (m), l_xx (n*n),
+ * l_ux (m*n), l_uu (m*m), E = 2n^2 + 2nm + n + m + m^2 (the ILQR_LIN record); term [B][n + n*n]: V_x, V_xx at
+ * t = N (l_f_x, l_f_xx, iLQR_class.py:136-138).  Outputs as ilqr_backward_pass; cfg->mu applies.  The system the
+ * handle was created for only fixes (n_x, n_u). */
+int ilqr_backward_tensors(ilqr_handle h, const void* lin, const void* term, void* U_ff_out, void* K_out);
 /* iLQR.forward_pass(x_0, alpha, X_old, U_old, U_ff, K) -> (X_new, U_new, cost)  (iLQR_class.py:75, 193-247) */
 int ilqr_forward_pass(ilqr_handle h, const void* x0, double alpha, const void* X_old, const void* U_old,
                       const void* U_ff, const void* K, void* X_new, void* U_new, void* cost);

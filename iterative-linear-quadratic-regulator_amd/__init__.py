@@ -11,10 +11,10 @@ from . import _lib  # noqa: F401
 from .iLQR_class import iLQR, horizon_steps  # noqa: F401
 from .systems import (System, MyPendulum, MyUADoublePendulum, MyDoublePendulum,  # noqa: F401
                       MyLinearSystem)
-from .api import solve, SolveResult, MPCState, mpc_init, mpc_step, make_system  # noqa: F401
+from .api import solve, SolveResult, MPCState, mpc_init, mpc_step, make_system, RiccatiSweep  # noqa: F401
 from . import problems  # noqa: F401
 from . import dist  # noqa: F401
 
 __all__ = ["iLQR", "horizon_steps", "System", "MyPendulum", "MyUADoublePendulum", "MyDoublePendulum",
-           "MyLinearSystem", "solve", "SolveResult", "MPCState", "mpc_init", "mpc_step", "make_system",
+           "MyLinearSystem", "solve", "SolveResult", "MPCState", "mpc_init", "mpc_step", "make_system", "RiccatiSweep",
            "problems"]

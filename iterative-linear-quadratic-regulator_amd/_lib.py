@@ -36,7 +36,7 @@ SYMBOLS = (
     "ilqr_abi_version", "ilqr_device_count", "ilqr_param_count", "ilqr_is_supported", "ilqr_last_error",
     "ilqr_create", "ilqr_create_custom", "ilqr_destroy", "ilqr_sync", "ilqr_set_problem", "ilqr_set", "ilqr_get",
     "ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_forward", "ilqr_select", "ilqr_iterate",
-    "ilqr_solve", "ilqr_backward_pass", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
+    "ilqr_solve", "ilqr_backward_pass", "ilqr_backward_tensors", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
     "ilqr_mpc_run", "ilqr_status_reduce", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
 )
 
@@ -107,6 +107,7 @@ def load():
     lib.ilqr_iterate.argtypes = [vp, ci]
     lib.ilqr_solve.argtypes = [vp, vp, vp]
     lib.ilqr_backward_pass.argtypes = [vp, vp, vp, vp, vp]
+    lib.ilqr_backward_tensors.argtypes = [vp, vp, vp, vp, vp]
     lib.ilqr_forward_pass.argtypes = [vp, vp, cd, vp, vp, vp, vp, vp, vp, vp]
     lib.ilqr_eval_points.argtypes = [vp, ci, ci] + [vp] * 14
     lib.ilqr_mpc_reset.argtypes = [vp, vp, vp]
@@ -264,6 +265,15 @@ class Handle:
         uff = np.empty(self.shape(UFF), dtype=self.np_dtype)
         k = np.empty(self.shape(K), dtype=self.np_dtype)
         self._chk(self.lib.ilqr_backward_pass(self.h, _ptr(X_), _ptr(U_), _ptr(uff), _ptr(k)))
+        return uff, k
+
+    def backward_tensors(self, lin, term):
+        """Riccati sweep on a caller-supplied expansion: lin (B, N, E), term (B, n + n*n) -> (U_ff, K)."""
+        lin = self._in(lin, (self.B, self.N, self.E))
+        term = self._in(term, (self.B, self.n_x + self.n_x * self.n_x))
+        uff = np.empty(self.shape(UFF), dtype=self.np_dtype)
+        k = np.empty(self.shape(K), dtype=self.np_dtype)
+        self._chk(self.lib.ilqr_backward_tensors(self.h, _ptr(lin), _ptr(term), _ptr(uff), _ptr(k)))
         return uff, k
 
     def forward_pass(self, x0, alpha, X_old, U_old, U_ff, K_):

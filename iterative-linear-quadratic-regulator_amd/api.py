@@ -33,6 +33,56 @@ def make_system(dynamics, cost=None, dtype=np.float64):
     return _KINDS[kind](x_target=cost["x_target"], Q=cost["Q"], R=cost["R"], Q_f=cost["Q_f"], dtype=dtype, **d)
 
 
+class RiccatiSweep:
+    """The backward sweep as a stand-alone operator for callers that bring their own expansion (their autodiff, an
+    identified or time-varying linear model): ``K, k = sweep(f_x, f_u, l_x, l_u, l_xx, l_ux, l_uu, V_x, V_xx)`` =
+    the reverse scan of ``iLQR.backward_pass`` (iLQR_class.py:136-151) without the linearisation in front of it.
+
+    Shapes (batch B, horizon N): f_x (B,N,n,n), f_u (B,N,n,m), l_x (B,N,n), l_u (B,N,m), l_xx (B,N,n,n),
+    l_ux (B,N,m,n), l_uu (B,N,m,m), V_x (B,n), V_xx (B,n,n).  Returns K (B,N,m,n) and k = U_ff (B,m,N).
+
+    The kernels exist for (n, m) in {(2,1), (4,1), (4,2), (8,4), (16,8)}; any n <= 16, m <= 8 is embedded in the
+    next one by padding with states that have no dynamics and no cost and controls with unit curvature (l_uu = 1)
+    and no effect -- their gains come out exactly zero and the original block's arithmetic is unchanged.
+    """
+
+    DIMS = ((2, 1), (4, 1), (4, 2), (8, 4), (16, 8))
+
+    def __init__(self, n_x, n_u, N, batch, dtype=np.float64, mu=0.0, device=0):
+        from . import _lib
+        fit = [d for d in self.DIMS if d[0] >= n_x and d[1] >= n_u]
+        if not fit:
+            raise ValueError(f"no sweep kernel holds n_x = {n_x}, n_u = {n_u} (limits 16, 8)")
+        self.n, self.m = int(n_x), int(n_u)
+        self.np_, self.mp = fit[0]
+        self.N, self.B, self.dtype = int(N), int(batch), np.dtype(dtype)
+        n, m = self.np_, self.mp
+        # the handle's system only fixes the dimensions: a linear system with neutral parameters
+        params = np.zeros(n * n + n * m + n + 2 * n * n + m * m)
+        self._h = _lib.Handle(system=_lib.SYS_LINEAR, n_x=n, n_u=m, horizon=self.N, batch=self.B, params=params,
+                              dt=1.0, integrator="discrete", dtype=self.dtype, mu=mu, device=device)
+
+    def __call__(self, f_x, f_u, l_x, l_u, l_xx, l_ux, l_uu, V_x, V_xx):
+        B, N, n, m, P, Q = self.B, self.N, self.n, self.m, self.np_, self.mp
+        dt = self.dtype
+
+        def pad(a, shape, tail):
+            a = np.asarray(a, dtype=dt).reshape((B,) + shape)
+            out = np.zeros((B,) + tail, dtype=dt)
+            out[tuple(slice(0, k) for k in a.shape)] = a
+            return out
+
+        fx, fu = pad(f_x, (N, n, n), (N, P, P)), pad(f_u, (N, n, m), (N, P, Q))
+        lx, lu = pad(l_x, (N, n), (N, P)), pad(l_u, (N, m), (N, Q))
+        lxx, lux, luu = pad(l_xx, (N, n, n), (N, P, P)), pad(l_ux, (N, m, n), (N, Q, P)), pad(l_uu, (N, m, m), (N, Q, Q))
+        for j in range(m, Q):
+            luu[:, :, j, j] = 1.0
+        lin = np.concatenate([a.reshape(B, N, -1) for a in (fx, fu, lx, lu, lxx, lux, luu)], axis=2)
+        term = np.concatenate([pad(V_x, (n,), (P,)), pad(V_xx, (n, n), (P, P)).reshape(B, -1)], axis=1)
+        uff, K = self._h.backward_tensors(lin, term)
+        return K[:, :, :m, :n], uff[:, :m, :]
+
+
 @dataclass
 class SolveResult:
     X: np.ndarray        # ([B,] n_x, N+1)

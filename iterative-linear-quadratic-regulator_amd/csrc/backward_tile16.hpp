@@ -683,4 +683,15 @@ __global__ void tile16_gather_dense_kernel(T* dense, const T* lin, int B, int N)
     dense[idx] = lin[((size_t)t * B + b) * kTile16 + tile16_index_of(e)];
 }
 
+// inverse: dense ILQR_LIN records -> tiles (the two pad scalars of a tile are zeroed by the caller's memset)
+template <typename T>
+__global__ void tile16_scatter_dense_kernel(const T* dense, T* lin, int B, int N) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * N * 46) return;
+    const int e = (int)(idx % 46);
+    const int t = (int)((idx / 46) % N);
+    const int b = (int)(idx / ((size_t)46 * N));
+    lin[((size_t)t * B + b) * kTile16 + tile16_index_of(e)] = dense[idx];
+}
+
 }  // namespace ilqr

@@ -201,6 +201,10 @@ int ilqr_solve(ilqr_handle h, int32_t* iters_out, void* cost_out) { ILQR_FWD(h, 
 int ilqr_backward_pass(ilqr_handle h, const void* X, const void* U, void* U_ff_out, void* K_out) {
     ILQR_FWD(h, backward_pass(X, U, U_ff_out, K_out));
 }
+
+int ilqr_backward_tensors(ilqr_handle h, const void* lin, const void* term, void* U_ff_out, void* K_out) {
+    ILQR_FWD(h, backward_tensors(lin, term, U_ff_out, K_out));
+}
 int ilqr_forward_pass(ilqr_handle h, const void* x0, double alpha, const void* X_old, const void* U_old,
                       const void* U_ff, const void* K, void* X_new, void* U_new, void* cost) {
     ILQR_FWD(h, forward_pass(x0, alpha, X_old, U_old, U_ff, K, X_new, U_new, cost));

@@ -38,6 +38,7 @@ struct SolverBase {
     virtual int iterate(int n) = 0;
     virtual int solve(int32_t* iters, void* cost) = 0;
     virtual int backward_pass(const void* X, const void* U, void* Uff, void* K) = 0;
+    virtual int backward_tensors(const void* lin, const void* term, void* Uff, void* K) = 0;
     virtual int forward_pass(const void* x0, double alpha, const void* X, const void* U, const void* Uff,
                              const void* K, void* Xn, void* Un, void* cost) = 0;
     virtual int eval_points(int integ, int npts, const void* x, const void* u, void** outs) = 0;
@@ -544,6 +545,23 @@ template <typename T> class SolverT : public SolverBase {
         return check_launch();
     }
 
+    // dense [B][N][E] expansion records -> the layout the backward kernel of this (n_x, n_u) reads
+    int up_lin(const void* host, T* lin) {
+        const size_t n = (size_t)B * N * E;
+        if (ops.lin_aos) {
+            ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(gains_scatter_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, E, E);
+            ILQR_HIPCHK(hipStreamSynchronize(stream));
+            return check_launch();
+        }
+        if (!ops.tile16) return up_tc(host, lin, E, N);
+        ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
+        ILQR_HIPCHK(hipMemsetAsync(lin, 0, (size_t)N * B * kTile16 * sizeof(T), stream));
+        hipLaunchKernelGGL(tile16_scatter_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
+        ILQR_HIPCHK(hipStreamSynchronize(stream));
+        return check_launch();
+    }
+
     int zero_solver_state(DeviceState<T>& s) {
         const size_t b = B;
         ILQR_HIPCHK(hipMemsetAsync(s.X, 0, (size_t)s.n_slots * (N + 1) * NX * b * sizeof(T), stream));
@@ -782,6 +800,19 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = up_ct(X, fn.X, nullptr, NX, N + 1))) return rc;
         if ((rc = up_ct(U, fn.U, nullptr, NU, N))) return rc;
         if ((rc = do_linearize(fn))) return rc;
+        if ((rc = do_backward(fn))) return rc;
+        if (Uff && (rc = down_gain_k(Uff, fn.gains))) return rc;
+        if (K && (rc = down_gain_K(K, fn.gains))) return rc;
+        return sync();
+    }
+
+    // the Riccati sweep alone, on an expansion the caller computed (its own autodiff, identified model, ...)
+    int backward_tensors(const void* lin, const void* term, void* Uff, void* K) override {
+        if (!lin || !term) { err = "backward_tensors: NULL input"; return ILQR_ERR_INVALID_ARG; }
+        int rc;
+        if ((rc = ensure_fn()) || (rc = reset_fn())) return rc;
+        if ((rc = up_lin(lin, fn.lin))) return rc;
+        if ((rc = up_tc(term, fn.term, NX + NX * NX, 1))) return rc;
         if ((rc = do_backward(fn))) return rc;
         if (Uff && (rc = down_gain_k(Uff, fn.gains))) return rc;
         if (K && (rc = down_gain_K(K, fn.gains))) return rc;

@@ -69,6 +69,29 @@ def backward_pass(sys, X, U, mu=0.0, return_value=False):
     return U_ff, K
 
 
+class _Record:
+    """One expansion record seen through the System interface backward_step reads."""
+
+    def __init__(self, rec, dtype):
+        self._r, self.dtype = rec, np.dtype(dtype)
+        self.n_u = rec["l_u"].shape[0]
+        for name in ("f_x", "f_u", "l_x", "l_u", "l_xx", "l_ux", "l_uu"):
+            setattr(self, name, (lambda v: (lambda x, u: v))(np.asarray(rec[name], dtype=dtype)))
+
+
+def backward_tensors(f_x, f_u, l_x, l_u, l_xx, l_ux, l_uu, V_x, V_xx, mu=0.0, dtype=np.float64):
+    """The reverse scan of iLQR_class.py:136-151 on a given expansion (one trajectory):
+    f_x (N,n,n), f_u (N,n,m), l_x (N,n), l_u (N,m), l_xx (N,n,n), l_ux (N,m,n), l_uu (N,m,m), V_x (n), V_xx (n,n)
+    -> U_ff (m,N), K (N,m,n).  Same step function as backward_pass."""
+    N, n, m = f_u.shape
+    V_x, V_xx = np.asarray(V_x, dtype=dtype), np.asarray(V_xx, dtype=dtype)
+    U_ff, K = np.zeros((m, N), dtype=dtype), np.zeros((N, m, n), dtype=dtype)
+    for t in range(N - 1, -1, -1):
+        rec = _Record(dict(f_x=f_x[t], f_u=f_u[t], l_x=l_x[t], l_u=l_u[t], l_xx=l_xx[t], l_ux=l_ux[t], l_uu=l_uu[t]), dtype)
+        K[t], U_ff[:, t], V_x, V_xx = backward_step(rec, None, None, V_x, V_xx, mu)
+    return U_ff, K
+
+
 def forward_pass(sys, x_0, alpha, X_old, U_old, U_ff, K):
     """Rollout with the affine control law (iLQR_class.py:164-247).
 

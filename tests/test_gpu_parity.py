@@ -399,3 +399,56 @@ def test_c4_mpc_instances_at_shard_size():
             np.testing.assert_allclose(costs[k, b], r["cost"], rtol=RTOL)
             U_guess = np.concatenate([r["U"][:, 1:], r["U"][:, -1:]], axis=1)
             state = (r["X"], r["U_ff"], r["K"])
+
+
+def _random_expansion(B, N, n, m, seed, dtype):
+    """Time-varying, mildly contracting dynamics and positive-definite costs with cross terms."""
+    rng = np.random.default_rng(seed)
+    rd = lambda a: a.astype(dtype).astype(np.float64)
+    f_x = rd(np.eye(n) * 0.95 + rng.standard_normal((B, N, n, n)) * (0.3 / np.sqrt(n)))
+    f_u = rd(rng.standard_normal((B, N, n, m)) * 0.5)
+    W = rng.standard_normal((B, N, n + m, n + m)) * 0.3
+    H = W @ np.swapaxes(W, -1, -2) + np.eye(n + m) * 0.5
+    l_xx, l_ux, l_uu = rd(H[..., :n, :n]), rd(H[..., n:, :n]), rd(H[..., n:, n:])
+    l_x, l_u = rd(rng.standard_normal((B, N, n))), rd(rng.standard_normal((B, N, m)))
+    Wf = rng.standard_normal((B, n, n))
+    V_xx, V_x = rd(Wf @ np.swapaxes(Wf, -1, -2) + np.eye(n)), rd(rng.standard_normal((B, n)))
+    return f_x, f_u, l_x, l_u, l_xx, l_ux, l_uu, V_x, V_xx
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,m,N", [(4, 1, 120), (2, 1, 50), (4, 2, 60), (3, 2, 40), (5, 1, 30), (6, 3, 30), (16, 8, 40),
+                                   (11, 5, 25)])
+def test_riccati_sweep_on_caller_supplied_tensors(n, m, N, dtype):
+    """ilqr_backward_tensors: the sweep alone on an expansion the caller brings (generic / LQ mode), for the
+    native kernel sizes and for sizes embedded by padding; K_t, k_t at rtol 1e-5 in both precisions."""
+    from oracle.ilqr import backward_tensors
+    B = 6
+    ex = _random_expansion(B, N, n, m, seed=100 + n * 10 + m, dtype=dtype)
+    sweep = ilqr_amd.RiccatiSweep(n, m, N, B, dtype=dtype)
+    K, k = sweep(*ex)
+    assert K.shape == (B, N, m, n) and k.shape == (B, m, N) and K.dtype == dtype
+    for b in range(B):
+        k_o, K_o = backward_tensors(*[a[b] for a in ex])
+        _close(K[b], K_o, RTOL, f"K n={n} m={m}")
+        _close(k[b], k_o, RTOL, f"k n={n} m={m}")
+
+
+def test_tensor_sweep_reproduces_the_system_sweep():
+    """Feeding the library's own linearisation (ILQR_LIN + the terminal derivatives) back through
+    ilqr_backward_tensors gives bit-identical gains to ilqr_backward_pass: same kernel, same bytes."""
+    p = _specs()["ua"]
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"])
+    N, B = p["N"], 4
+    X, U = _rand_traj(4, 1, N, B, seed=2, scale=0.5)
+    s = ilqr_amd.iLQR(sysm, None, X[:, :, 0], U, N=N, verbose=False)
+    uff, K = s.backward_pass(X, U)
+    h = s.handle
+    h.set(_lib.X, X)
+    h.set(_lib.U, U)
+    h.linearize()
+    lin = h.get(_lib.LIN)
+    term = np.stack([np.concatenate([sysm.l_f_x_fcn(X[b, :, -1]), sysm.l_f_xx_fcn(X[b, :, -1]).ravel()]) for b in range(B)])
+    uff2, K2 = h.backward_tensors(lin, term)
+    np.testing.assert_array_equal(K2, K)
+    np.testing.assert_array_equal(uff2, uff)
