@@ -609,15 +609,22 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     cp.start();
     T cost = T(0);
     T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + bb;
-    T* Uc = a.U + ((size_t)cslot * N * NU) * B + bb;
     const int rowB = (int)(B * sizeof(T));
-    const i32x4 srdX = make_srd(a.X, (unsigned)((size_t)a.n_slots * (N + 1) * NX * B * sizeof(T)));
-    const i32x4 srdU = make_srd(a.U, (unsigned)((size_t)a.n_slots * N * NU * B * sizeof(T)));
-    const i32x4 srdG = make_srd(a.gains, (unsigned)((size_t)N * B * R * sizeof(T)));
+    const unsigned bytesX = (unsigned)((size_t)a.n_slots * (N + 1) * NX * B * sizeof(T));
+    const unsigned bytesU = (unsigned)((size_t)a.n_slots * N * NU * B * sizeof(T));
+    // candidate stores go through buffer descriptors: the time step moves in the scalar offset (no per-store
+    // 64-bit VALU address arithmetic), and a dead lane's offset lies beyond the descriptor's range, where the
+    // hardware drops the store (no exec-mask juggling around the counted stores)
+    // (the same descriptors serve the ring's asm loads: one set of SGPRs)
+    const __amdgpu_buffer_rsrc_t rXc = make_rsrc(a.X, bytesX), rUc = make_rsrc(a.U, bytesU);
+    const int kDropped = 0x7ffffff0;
+    const int vXc = live ? (int)(((size_t)cslot * (N + 1) * NX * B + bb) * sizeof(T)) : kDropped;
+    const int vUc = live ? (int)(((size_t)cslot * N * NU * B + bb) * sizeof(T)) : kDropped;
+    const __amdgpu_buffer_rsrc_t srdG = make_rsrc(a.gains, (unsigned)((size_t)N * B * R * sizeof(T)));
     const int vx = (int)(((size_t)slot * (N + 1) * NX * B + bb) * sizeof(T));
     const int vu = (int)(((size_t)slot * N * NU * B + bb) * sizeof(T));
     const int vg = (int)((size_t)bb * R * sizeof(T));
-    auto issue = [&](In& in, int t) { in.issue(srdX, srdU, srdG, vx, vu, vg, t * NX * rowB, t * NU * rowB, t * R * rowB, rowB); };
+    auto issue = [&](In& in, int t) { in.issue(rXc, rUc, srdG, vx, vu, vg, t * NX * rowB, t * NU * rowB, t * R * rowB, rowB); };
     auto do_step = [&](const In& in, int t) {
         T dx[NX];
 #pragma unroll
@@ -631,11 +638,9 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
         }
         // exactly NX + NU stores per step for every wave that is still running (they are counted)
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (live) Xc[((size_t)t * NX + i) * B] = x[i];
+        for (int i = 0; i < NX; ++i) buf_store1(rXc, vXc, uniform((t * NX + i) * rowB), x[i]);
 #pragma unroll
-        for (int j = 0; j < NU; ++j)
-            if (live) Uc[((size_t)t * NU + j) * B] = u[j];
+        for (int j = 0; j < NU; ++j) buf_store1(rUc, vUc, uniform((t * NU + j) * rowB), u[j]);
         cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
         T xn[NX];
         Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);
