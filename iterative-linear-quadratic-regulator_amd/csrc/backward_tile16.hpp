@@ -444,6 +444,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     const int st = a.status[b];
     const bool act = valid && traj_active(st);
     if (__ballot(act) == 0ull) return;
+    if (a.reset_slots && act && l16 == 0) a.cur_slot[b] = 0;   // see linearize_kernel: the trajectory now lives in slot 0
     ClockProbe cp;
     cp.start();
     const size_t B = a.B;
@@ -587,6 +588,7 @@ __global__ void __launch_bounds__(64) backward_tile16_lds_kernel(KArgs<T> a) {
     const int st = a.status[b];
     const bool act = valid && traj_active(st);
     if (__ballot(act) == 0ull) return;
+    if (a.reset_slots && act && l16 == 0) a.cur_slot[b] = 0;   // see linearize_kernel: the trajectory now lives in slot 0
     ClockProbe cp;
     cp.start();
     const size_t B = a.B;

@@ -18,31 +18,64 @@
 
 namespace ilqr {
 
-// Lean sin/cos pair: Cody-Waite reduction by pi/2 in three FMA steps, then the fdlibm (double) /
-// cephes (float) kernel polynomials on [-pi/4, pi/4] and a quadrant select.  Branch-free, ~30
-// instructions for BOTH values (the libm entry points carry a Payne-Hanek slow path and a branch per
-// call, which dominated the rollout's instruction stream).  Accuracy (checked on the CPU against libm
-// with the same constants): <= 1 ulp in double, <= 1.5 ulp in float for |x| < 1e3, graceful beyond --
-// pendulum angles never leave that range on a rollout whose cost is still finite.
+// Lean sin/cos pair, branch-free, both values from one reduction (the libm entry points carry a Payne-Hanek
+// slow path and a branch per call, which dominated the rollout's instruction stream).
+//   double: Cody-Waite reduction by pi/2 in three FMA steps, the fdlibm kernel polynomials on [-pi/4, pi/4]
+//           and a quadrant select; <= 1 ulp for |x| < 1e3.
+//   float:  reduction by pi (n from the 1.5*2^23 rounding constant, so no rndne / cvt), minimax polynomials
+//           on [-pi/2, pi/2], and ONE sign for both values (sin(r + n pi) = (-1)^n sin r, same for cos) taken
+//           straight from the low bit of the rounding constant's sum.  Reducing by pi/2 instead costs a
+//           quadrant select of ~11 integer / compare / select instructions per angle -- measured at 22 % of the
+//           RK4 rollout's instruction stream -- against two more FMAs here.  Absolute error <= 1.1e-7 (sin),
+//           1.5e-7 (cos) for |x| < 1e3 (checked against libm on the CPU with the same constants; the pi/2 form
+//           had 0.9e-7), graceful beyond -- pendulum angles never leave that range on a rollout whose cost is
+//           still finite.  sincos2 evaluates two angles in packed FP32 (v_pk_fma_f32: two lanes' worth of FMA
+//           per issue slot) with exactly the arithmetic of sincos, so both give bit-identical results.
 template <typename T> struct M;
 template <> struct M<float> {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     static ILQR_DEV float sqrt(float x) { return sqrtf(x); }
     static ILQR_DEV float abs(float x) { return fabsf(x); }
+    static constexpr float kMagic = 12582912.0f;             // 1.5 * 2^23: x/pi + kMagic rounds to nearest int
+    static constexpr float kInvPi = 0x1.45f306p-2f;
+    static constexpr float kPiHi = 0x1.921fb6p+1f, kPiMid = -0x1.777a5cp-24f, kPiLo = -0x1.ee59dap-49f;
+    static constexpr float kS0 = -0x1.555548p-3f, kS1 = 0x1.110e42p-7f, kS2 = -0x1.9f588ap-13f, kS3 = 0x1.5c90a2p-19f;
+    static constexpr float kC0 = -0.5f, kC1 = 0x1.555546p-5f, kC2 = -0x1.6c134cp-10f, kC3 = 0x1.9f68bp-16f,
+                           kC4 = -0x1.17b08ap-22f;
     static ILQR_DEV void sincos(float x, float* sn, float* cs) {
-        const float n = rintf(x * 0x1.45f306p-1f);
-        float r = fmaf(-n, 0x1.921fb6p+0f, x);
-        r = fmaf(-n, -0x1.777a5cp-25f, r);
-        r = fmaf(-n, -0x1.ee59dap-50f, r);
+        const float t = fmaf(x, kInvPi, kMagic);
+        const float n = t - kMagic;
+        float r = fmaf(-n, kPiHi, x);
+        r = fmaf(-n, kPiMid, r);
+        r = fmaf(-n, kPiLo, r);
         const float z = r * r;
-        const float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+        const float ps = fmaf(fmaf(fmaf(kS3, z, kS2), z, kS1), z, kS0);
         const float s = fmaf(r * z, ps, r);
-        const float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
-        const float c = fmaf(z * z, pc, fmaf(-0.5f, z, 1.0f));
-        const int q = (int)n;
-        const float a = (q & 1) ? c : s;
-        const float b = (q & 1) ? s : c;
-        *sn = (q & 2) ? -a : a;
-        *cs = ((q + 1) & 2) ? -b : b;
+        const float pc = fmaf(fmaf(fmaf(fmaf(kC4, z, kC3), z, kC2), z, kC1), z, kC0);
+        const float c = fmaf(z, pc, 1.0f);
+        const unsigned sign = __float_as_uint(t) << 31;      // parity of n
+        *sn = __uint_as_float(__float_as_uint(s) ^ sign);
+        *cs = __uint_as_float(__float_as_uint(c) ^ sign);
+    }
+    static ILQR_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+    static ILQR_DEV f2 splat(float v) { f2 r; r.x = v; r.y = v; return r; }
+    static ILQR_DEV void sincos2(float x0, float x1, float* s0, float* c0, float* s1, float* c1) {
+        f2 x; x.x = x0; x.y = x1;
+        const f2 t = fma2(x, splat(kInvPi), splat(kMagic));
+        const f2 n = t - splat(kMagic);
+        f2 r = fma2(-n, splat(kPiHi), x);
+        r = fma2(-n, splat(kPiMid), r);
+        r = fma2(-n, splat(kPiLo), r);
+        const f2 z = r * r;
+        const f2 ps = fma2(fma2(fma2(splat(kS3), z, splat(kS2)), z, splat(kS1)), z, splat(kS0));
+        const f2 s = fma2(r * z, ps, r);
+        const f2 pc = fma2(fma2(fma2(fma2(splat(kC4), z, splat(kC3)), z, splat(kC2)), z, splat(kC1)), z, splat(kC0));
+        const f2 c = fma2(z, pc, splat(1.0f));
+        const unsigned g0 = __float_as_uint(t.x) << 31, g1 = __float_as_uint(t.y) << 31;
+        *s0 = __uint_as_float(__float_as_uint(s.x) ^ g0);
+        *c0 = __uint_as_float(__float_as_uint(c.x) ^ g0);
+        *s1 = __uint_as_float(__float_as_uint(s.y) ^ g1);
+        *c1 = __uint_as_float(__float_as_uint(c.y) ^ g1);
     }
 };
 template <> struct M<double> {
@@ -73,6 +106,10 @@ template <> struct M<double> {
         const double b = (q & 1) ? s : c;
         *sn = (q & 2) ? -a : a;
         *cs = ((q + 1) & 2) ? -b : b;
+    }
+    static ILQR_DEV void sincos2(double x0, double x1, double* s0, double* c0, double* s1, double* c1) {
+        sincos(x0, s0, c0);
+        sincos(x1, s1, c1);
     }
 };
 
@@ -141,8 +178,7 @@ template <typename T, int NU_> struct DoublePendulum {
         const T q1 = x[0], q2 = x[1], q1d = x[2], q2d = x[3];
         // sin(q1 + q2) by the addition theorem: two reductions per evaluation instead of three
         T s1, c1, s2, c2;
-        M<T>::sincos(q1, &s1, &c1);
-        M<T>::sincos(q2, &s2, &c2);
+        M<T>::sincos2(q1, q2, &s1, &c1, &s2, &c2);
         const T s12 = s1 * c2 + c1 * s2;
         const T m11 = c11 + a * c2, m12 = c12 + T(0.5) * a * c2, m22 = c12;
         const T as2 = a * s2;
@@ -161,8 +197,7 @@ template <typename T, int NU_> struct DoublePendulum {
         const T a = p[0], c11 = p[1], c12 = p[2], gA = p[3], gB = p[4], d1 = p[5], d2 = p[6];
         const T q1 = x[0], q2 = x[1], q1d = x[2], q2d = x[3];
         T s1, c1, s2, c2;
-        M<T>::sincos(q1, &s1, &c1);
-        M<T>::sincos(q2, &s2, &c2);
+        M<T>::sincos2(q1, q2, &s1, &c1, &s2, &c2);
         const T s12 = s1 * c2 + c1 * s2, c12q = c1 * c2 - s1 * s2;
         const T m11 = c11 + a * c2, m12 = c12 + T(0.5) * a * c2, m22 = c12;
         const T as2 = a * s2, ac2 = a * c2;

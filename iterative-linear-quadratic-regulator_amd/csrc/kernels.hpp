@@ -13,7 +13,8 @@
 //
 // "Slots": the current trajectory of b lives in slot cur_slot[b]; candidate a of a
 // line-search pass is rolled out into slot (cur_slot[b] + 1 + a) % n_slots, and accepting
-// a candidate is just cur_slot[b] <- that slot: no trajectory is ever copied.
+// a candidate is just cur_slot[b] <- that slot.  The next linearize (which reads every point
+// anyway) moves the accepted trajectories back to slot 0, so rollouts stay coalesced.
 #pragma once
 #include "dynamics.hpp"
 
@@ -41,6 +42,7 @@ template <typename T> struct KArgs {
     T* gains; T* lin; T* term; T* x0;
     T* costs; T* cost; T* cost_prev; T* alpha_taken;
     int* status; int* iters; int* accepted; int* counters;
+    int reset_slots;   // backward kernels: set cur_slot[b] = 0 for active b (after a canonicalising linearize)
     const T* params;
     long long* probe;  // diagnostic: {shader cycles, 100 MHz ticks} of block 0 per kernel, or nullptr
 };
@@ -90,19 +92,52 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     const size_t B = a.B;
     const int t = (int)(idx / B);
     const int b = (int)(idx % B);
-    const bool live = t <= a.N && traj_active(a.status[b]);
-    if constexpr (!TILE16) {
-        if (!live) return;
-    }
+    const bool inr = t <= a.N;                                  // a (b, t) point of the batch
+    const bool live = inr && traj_active(a.status[b]);
     const T* __restrict__ p = a.params;
     T x[NX], u[NU];
-    int slot = 0;
-    if (live) slot = a.cur_slot[b];
+    // Canonicalisation: accepting a candidate only moves cur_slot[b] (no copy), so after a few iterations
+    // neighbouring trajectories live in different slots and every wave-wide access of the rollout -- 64
+    // consecutive b -- scatters over up to n_slots rows (measured: rollout 125 -> 200 us once the slots have
+    // decorrelated).  This kernel reads every point of the active trajectories anyway: it also writes them into
+    // slot 0 (16 MB at the c3 shape).  cur_slot[b] itself may only change once every block has read it, so that
+    // is left to the kernel that always follows (the backward sweep, KArgs::reset_slots; SolverT::fix_slots for
+    // any other order); the old slot keeps a valid copy until the next rollout overwrites it.
+    const int slot = live ? a.cur_slot[b] : 0;
+    const bool move = live && slot != 0;
     const int tt = live ? t : 0;
     const int bb = live ? b : 0;
     const T* Xp = a.X + (((size_t)slot * (a.N + 1) + tt) * NX) * B + bb;
+    if (live) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = Xp[(size_t)i * B];
+        for (int i = 0; i < NX; ++i) x[i] = Xp[(size_t)i * B];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = T(0);
+    }
+    if (move) {
+        T* X0 = a.X + ((size_t)tt * NX) * B + bb;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) X0[(size_t)i * B] = x[i];
+    }
+    const bool has_u = inr && t < a.N;
+    const int tu = has_u ? t : 0;
+    const T* Up = a.U + (((size_t)slot * a.N + tu) * NU) * B + bb;
+    if (has_u && live) {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = Up[(size_t)i * B];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = T(0);
+    }
+    if (has_u && move) {
+        T* U0 = a.U + ((size_t)tu * NU) * B + bb;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) U0[(size_t)i * B] = u[i];
+    }
+    if constexpr (!TILE16) {
+        if (!live) return;
+    }
     if (live && t == a.N) {
         T g[NX], H[NX][NX];
         Cost<T, Dyn>::l_f_x(p, x, g);
@@ -114,10 +149,6 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
         if constexpr (!TILE16) return;
     }
     const bool point = live && t < a.N;   // this lane produces an expansion record
-    const int tu = point ? t : 0;
-    const T* Up = a.U + (((size_t)slot * a.N + tu) * NU) * B + bb;
-#pragma unroll
-    for (int i = 0; i < NU; ++i) u[i] = Up[(size_t)i * B];
     T xn[NX], fx[NX][NX], fu[NX][NU];
     Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);  // integrator folded at compile time
     if constexpr (TILE16) {
@@ -207,6 +238,13 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     for (int i = 0; i < NU * NX; ++i) out[(size_t)(e++) * B] = lux[i / NX][i % NX];
 #pragma unroll
     for (int i = 0; i < NU * NU; ++i) out[(size_t)(e++) * B] = luu[i / NU][i % NU];
+}
+
+// after a canonicalising linearize that is NOT followed by a backward sweep (stage API used out of order)
+template <typename T>
+__global__ void reset_slots_kernel(KArgs<T> a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < a.B && traj_active(a.status[b])) a.cur_slot[b] = 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -431,6 +469,7 @@ __global__ void __launch_bounds__(64) backward_lane_kernel(KArgs<T> a) {
     if (b >= a.B) return;
     const int st = a.status[b];
     if (!traj_active(st)) return;
+    if (a.reset_slots) a.cur_slot[b] = 0;   // linearize moved this trajectory into slot 0 (see linearize_kernel)
     const size_t B = a.B;
     T Vx[NX], Vxx[NX][NX];
 #pragma unroll

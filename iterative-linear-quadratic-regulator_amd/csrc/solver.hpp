@@ -93,6 +93,7 @@ template <typename T> struct Ops {
     int lin_stride = 0;   // scalars per (b, t) in the expansion buffer
     bool tile16 = false;  // expansion packed as 48-scalar tiles (n_x = 4, n_u = 1)
     bool lin_aos = false; // expansion stored as [N][B][E] records (n_x > 4, wave-cooperative kernels)
+    bool canonical = false;  // linearize moves every current trajectory into slot 0 (then cur_slot is reset)
 };
 
 // linearize / forward are compiled once per integrator so the integrator switch folds away and each
@@ -138,6 +139,7 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
     Ops<T> o;
     constexpr bool TILE = (NX == 4 && NU == 1);
     o.tile16 = TILE;
+    o.canonical = true;
     o.lin_stride = TILE ? kTile16 : (2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU);
     set_integrator_ops<T, Dyn, TILE, 0>(o);
     set_integrator_ops<T, Dyn, TILE, 1>(o);
@@ -329,6 +331,7 @@ template <typename T> struct DeviceState {
     T *X = nullptr, *U = nullptr, *gains = nullptr, *lin = nullptr, *term = nullptr, *x0 = nullptr;
     T *costs = nullptr, *cost = nullptr, *cost_prev = nullptr, *alpha_taken = nullptr;
     int *cur_slot = nullptr, *status = nullptr, *iters = nullptr, *accepted = nullptr, *counters = nullptr;
+    bool slots_stale = false;   // linearize has moved the active trajectories to slot 0, cur_slot not yet reset
 };
 
 template <typename T> class SolverT : public SolverBase {
@@ -455,6 +458,7 @@ template <typename T> class SolverT : public SolverBase {
         a.X = s.X; a.U = s.U; a.cur_slot = s.cur_slot; a.gains = s.gains; a.lin = s.lin; a.term = s.term;
         a.x0 = s.x0; a.costs = s.costs; a.cost = s.cost; a.cost_prev = s.cost_prev; a.alpha_taken = s.alpha_taken;
         a.status = s.status; a.iters = s.iters; a.accepted = s.accepted; a.counters = s.counters; a.params = params;
+        a.reset_slots = 0;
         a.probe = probe_on ? probe : nullptr;
         return a;
     }
@@ -609,6 +613,7 @@ template <typename T> class SolverT : public SolverBase {
         if (!src) { err = "set: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
         const size_t want = field_bytes(field);
         if (want == 0 || bytes != want) { err = "set: unknown field or wrong byte count"; return ILQR_ERR_INVALID_ARG; }
+        if (int rcs = fix_slots(st)) return rcs;
         switch (field) {
             case ILQR_X: return up_ct(src, st.X, st.cur_slot, NX, N + 1);
             case ILQR_U: return up_ct(src, st.U, st.cur_slot, NU, N);
@@ -624,6 +629,7 @@ template <typename T> class SolverT : public SolverBase {
         if (!dst) { err = "get: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
         const size_t want = field_bytes(field);
         if (want == 0 || bytes != want) { err = "get: unknown field or wrong byte count"; return ILQR_ERR_INVALID_ARG; }
+        if (int rcs = fix_slots(st)) return rcs;
         switch (field) {
             case ILQR_X: return down_ct(dst, st.X, st.cur_slot, NX, N + 1);
             case ILQR_U: return down_ct(dst, st.U, st.cur_slot, NU, N);
@@ -648,17 +654,30 @@ template <typename T> class SolverT : public SolverBase {
         timer.begin(ILQR_PHASE_LINEARIZE, stream);
         ops.linearize[cfg.integrator](a, stream);
         timer.end(stream);
+        s.slots_stale = ops.canonical;   // the sweep that follows resets cur_slot (KArgs::reset_slots)
+        return check_launch();
+    }
+    // cur_slot must be truthful before anything but the backward sweep looks at it
+    int fix_slots(DeviceState<T>& s) {
+        if (!s.slots_stale) return ILQR_OK;
+        KArgs<T> a = kargs(s);
+        hipLaunchKernelGGL(reset_slots_kernel<T>, dim3(grid_for((size_t)B)), dim3(256), 0, stream, a);
+        s.slots_stale = false;
         return check_launch();
     }
     int do_backward(DeviceState<T>& s) {
         KArgs<T> a = kargs(s);
+        a.reset_slots = s.slots_stale ? 1 : 0;
         timer.begin(ILQR_PHASE_BACKWARD, stream);
         ops.backward(a, stream);
         timer.end(stream);
+        s.slots_stale = false;
         return check_launch();
     }
     int do_forward(DeviceState<T>& s, const double* alphas, int n) {
         if (n < 1 || n > s.n_slots - 1 || n > kMaxAlpha) { err = "forward: alpha count out of range"; return ILQR_ERR_INVALID_ARG; }
+        int rcf = fix_slots(s);
+        if (rcf) return rcf;
         KArgs<T> a = kargs(s);
         a.n_pass = n;
         for (int i = 0; i < n; ++i) a.alphas[i] = (T)alphas[i];
@@ -668,6 +687,7 @@ template <typename T> class SolverT : public SolverBase {
         return check_launch();
     }
     int do_select(DeviceState<T>& s, const double* alphas, int n, bool last, bool init, int counter_idx) {
+        if (int rcs = fix_slots(s)) return rcs;
         KArgs<T> a = kargs(s);
         a.n_pass = n; a.last_pass = last; a.init_mode = init; a.counter_idx = counter_idx;
         for (int i = 0; i < n; ++i) a.alphas[i] = (T)alphas[i];
