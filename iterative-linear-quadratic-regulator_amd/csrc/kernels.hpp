@@ -22,7 +22,11 @@ namespace ilqr {
 
 // cache-policy switches (compile-time; A/B'd with tools/build_variants.sh, results in DESIGN.md)
 #ifndef ILQR_NT_TILE_STORE
-#define ILQR_NT_TILE_STORE 1   // measured: forward 216 -> 191 us (f32), 359 -> 340 us (f64), sweep unchanged
+// Non-temporal tile stores paid while the rollout's accesses were scattered over the slots (forward 216 -> 191 us):
+// the one-shot tile stream no longer evicted its re-read working set.  With the canonical slot 0 (linearize_kernel)
+// that working set is small and coalesced, and ordinary stores win: the sweep finds most of the 157 MB tile tensor in
+// the 256 MB Infinity Cache (42.8 -> 38.8 us f32, 95.9 -> 89.1 us f64; whole step 0.226 -> 0.223 ms).
+#define ILQR_NT_TILE_STORE 0
 #endif
 #ifndef ILQR_NT_TILE_LOAD
 #define ILQR_NT_TILE_LOAD 0
