@@ -124,6 +124,7 @@ template <typename T> struct Tile16 {
     T vj[4];   // f_u[j], l_x[j], l_ux[j], e_j
     T lxx;     // l_xx[i][j]
     T bi;      // f_u[i]
+    T luxi;    // l_ux[i]   (row form, for the transpose-free fp32 step)
 };
 
 template <typename T> ILQR_DEV void tile16_load(Tile16<T>& tl, const T* __restrict__ tp, int i, int j, int l16) {
@@ -136,6 +137,7 @@ template <typename T> ILQR_DEV void tile16_load(Tile16<T>& tl, const T* __restri
     tl.vj[0] = v.x; tl.vj[1] = v.y; tl.vj[2] = v.z; tl.vj[3] = v.w;
     tl.lxx = tp[16 + l16];
     tl.bi = tp[32 + 4 * i];
+    tl.luxi = tp[32 + 4 * i + 2];
 }
 
 template <typename T>
@@ -145,6 +147,7 @@ ILQR_DEV void tile16_load_buf(Tile16<T>& tl, __amdgpu_buffer_rsrc_t r, const Til
     BufLoad<32, T>::v4(r, o.vj, soff, tl.vj);      // f_u[j], l_x[j], l_ux[j], e_j
     tl.lxx = BufLoad<16, T>::v1(r, o.vl, soff);    // l_xx[i][j]
     tl.bi = BufLoad<32, T>::v1(r, o.vi, soff);     // f_u[i]
+    tl.luxi = BufLoad<34, T>::v1(r, o.vi, soff);   // l_ux[i]
 }
 
 // ---- tile loads hipcc does not count -------------------------------------------------------------------
@@ -184,8 +187,8 @@ template <typename T> struct RawTile;
 // load of the statement must not see its address register overwritten by an earlier one.
 template <> struct RawTile<float> {
     static constexpr int NLOAD = 5;
-    f32x4n ski, skj, vj;
-    float lxx, bi;
+    f32x4n ski, skj, vj, vi;   // vi = {f_u[i], l_x[i], l_ux[i], e_i}: the row-form twin of vj (f_u[i] and l_ux[i] used)
+    float lxx;
     ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
         asm volatile(
             "s_nop 4\n\t"
@@ -193,19 +196,19 @@ template <> struct RawTile<float> {
             "buffer_load_dwordx4 %1, %6, %8, %9 offen" ILQR_TILE_NT "\n\t"
             "buffer_load_dwordx4 %2, %6, %8, %9 offen offset:128" ILQR_TILE_NT "\n\t"
             "buffer_load_dword %3, %7, %8, %9 offen offset:64" ILQR_TILE_NT "\n\t"
-            "buffer_load_dword %4, %5, %8, %9 offen offset:128" ILQR_TILE_NT
-            : "=&v"(ski), "=&v"(skj), "=&v"(vj), "=&v"(lxx), "=&v"(bi)
+            "buffer_load_dwordx4 %4, %5, %8, %9 offen offset:128" ILQR_TILE_NT
+            : "=&v"(ski), "=&v"(skj), "=&v"(vj), "=&v"(lxx), "=&v"(vi)
             : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)
             : "memory");
     }
     template <int N> ILQR_DEV void wait() {
-        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ski), "+v"(skj), "+v"(vj), "+v"(lxx), "+v"(bi) : "i"(N) : "memory");
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ski), "+v"(skj), "+v"(vj), "+v"(lxx), "+v"(vi) : "i"(N) : "memory");
     }
     ILQR_DEV void unpack(Tile16<float>& t) const {
         t.ski[0] = ski.x; t.ski[1] = ski.y; t.ski[2] = ski.z; t.ski[3] = ski.w;
         t.skj[0] = skj.x; t.skj[1] = skj.y; t.skj[2] = skj.z; t.skj[3] = skj.w;
         t.vj[0] = vj.x; t.vj[1] = vj.y; t.vj[2] = vj.z; t.vj[3] = vj.w;
-        t.lxx = lxx; t.bi = bi;
+        t.lxx = lxx; t.bi = vi.x; t.luxi = vi.z;
     }
 };
 template <> struct RawTile<double> {
@@ -236,7 +239,7 @@ template <> struct RawTile<double> {
         t.ski[0] = ski0.x; t.ski[1] = ski0.y; t.ski[2] = ski1.x; t.ski[3] = ski1.y;
         t.skj[0] = skj0.x; t.skj[1] = skj0.y; t.skj[2] = skj1.x; t.skj[3] = skj1.y;
         t.vj[0] = vj0.x; t.vj[1] = vj0.y; t.vj[2] = vj1.x; t.vj[3] = vj1.y;
-        t.lxx = lxx; t.bi = bi;
+        t.lxx = lxx; t.bi = bi; t.luxi = 0.0;   // (row-form l_ux is only used by the fp32 step)
     }
 };
 
@@ -385,39 +388,62 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
 
 ILQR_DEV void tile16_step_f32(const Tile16<float>& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj,
                               float& kff, bool& pd) {
-    float P, pu, qx, qu, quu, Qxx, Qux, t;
-    ILQR_V_MUL(P, c.ski[0], V);                               //  1 A
-    ILQR_V_MUL(pu, c.bi, V);                                  //  2 B
-    ILQR_V_FMA(qx, c.skj[0], vx, c.vj[1]);                    //  3 C   Q_x = l_x + ...
-    ILQR_FMAC_DPP_NEXT(P, V, c.ski[1], "row_ror:12");         //  4 A
-    ILQR_V_ADD_DPP(t, pu, "row_ror:8");                       //  5 B   pu[i] + pu[i+2]
-    ILQR_FMAC_DPP_NEXT(qx, vx, c.skj[1], ILQR_QP1);           //  6 C
-    ILQR_FMAC_DPP_NEXT(P, V, c.ski[2], "row_ror:8");          //  7 A
-    ILQR_V_MUL(qu, c.vj[0], vx);                              //  8 C2  f_u[j] * V_x[j]
-    ILQR_FMAC_DPP_NEXT(qx, vx, c.skj[2], ILQR_QP2);           //  9 C
-    ILQR_FMAC_DPP_NEXT(P, V, c.ski[3], "row_ror:4");          // 10 A   P done
-    ILQR_V_ADD_DPP(pu, t, "row_ror:12");                      // 11 B   pu done (sum over the 4 rows)
-    ILQR_FMAC_DPP_NEXT(qx, vx, c.skj[3], ILQR_QP3);           // 12 C   Q_x done
-    ILQR_V_FMAC(qu, lc.m0, c.vj[3]);                          // 13 C2  + l_u on lane j = 0
-    ILQR_V_FMA(Qxx, c.skj[0], P, c.lxx);                      // 14 A   Q_xx = l_xx + ...
-    ILQR_V_FMA(Qux, c.skj[0], pu, c.vj[2]);                   // 15 B   Q_ux = l_ux + ...
-    ILQR_V_MUL(quu, pu, c.vj[0]);                             // 16 B2  pu[j] * f_u[j]
-    ILQR_FMAC_DPP_NEXT(Qxx, P, c.skj[1], ILQR_QP1);           // 17 A
-    ILQR_FMAC_DPP_NEXT(Qux, pu, c.skj[1], ILQR_QP1);          // 18 B
-    ILQR_V_FMAC(quu, lc.m1, c.vj[3]);                         // 19 B2  + l_uu on lane j = 1
-    ILQR_V_ADD_DPP(t, qu, ILQR_QSW);                          // 20 C2
-    ILQR_FMAC_DPP_NEXT(Qxx, P, c.skj[2], ILQR_QP2);           // 21 A
-    ILQR_FMAC_DPP_NEXT(Qux, pu, c.skj[2], ILQR_QP2);          // 22 B
-    ILQR_V_ADD_DPP(quu, quu, ILQR_QSW);                       // 23 B2
-    ILQR_V_ADD_DPP(qu, t, ILQR_QP2);                          // 24 C2  Q_u done
-    ILQR_FMAC_DPP_NEXT(Qxx, P, c.skj[3], ILQR_QP3);           // 25 A   Q_xx done
-    ILQR_FMAC_DPP_NEXT(Qux, pu, c.skj[3], ILQR_QP3);          // 26 B   Q_ux done
-    ILQR_V_ADD_DPP(quu, quu, ILQR_QP2);                       // 27 B2  Q_uu done
+    // Chain R computes Q_ux a second time in ROW form (lane (i, j) holds Q_ux[i]) instead of transposing the
+    // column form through the LDS crossbar at the end of the step (ds_bpermute + lgkmcnt wait sat on the critical
+    // path: ~50 cycles of a ~390-cycle step).  Row form needs pu[i] = sum_k f_u[k] V_xx[k][i] along the ROW, i.e.
+    // it reads V_xx[i][k] for V_xx[k][i]: V_xx is symmetric up to the rounding of its own update, so the two forms
+    // agree to an ulp-sized perturbation of V_xx (the reference does not symmetrise either).  Seven more
+    // instructions, all off the critical path, against one LDS round trip on it.
+    // The 34 instructions are ONE asm statement: between separate statements hipcc's hazard recogniser, which
+    // cannot see inside them, put a defensive s_nop in front of every third one (11 per step, ~10 % of a lone
+    // wave's issue slots).  Inside the block the order itself keeps every hazard: each operand was produced at
+    // least 3 instructions earlier (a DPP read needs 2 wait states behind its producer, a forwarded result 1).
+    float P, pu, pr, qx, qu, quu, Qxx, Qux, Quxi, t, t2;
+#define DPPT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile(
+        "v_mul_f32 %[P], %[si0], %[V]\n\t"                          //  1 A
+        "v_mul_f32 %[pu], %[bi], %[V]\n\t"                          //  2 B
+        "v_mul_f32 %[pr], %[vj0], %[V]\n\t"                         //  3 R   f_u[j] * V[i][j]
+        "v_fma_f32 %[qx], %[sj0], %[vx], %[vj1]\n\t"                //  4 C   Q_x = l_x + ...
+        "v_fmac_f32_dpp %[P], %[V], %[si1] row_ror:12" DPPT           //  5 A
+        "v_add_f32_dpp %[t], %[pu], %[pu] row_ror:8" DPPT             //  6 B   pu[i] + pu[i+2]
+        "v_add_f32_dpp %[t2], %[pr], %[pr] quad_perm:[1,0,3,2]" DPPT  //  7 R
+        "v_fmac_f32_dpp %[qx], %[vx], %[sj1] quad_perm:[1,2,3,0]" DPPT  //  8 C
+        "v_fmac_f32_dpp %[P], %[V], %[si2] row_ror:8" DPPT            //  9 A
+        "v_mul_f32 %[qu], %[vj0], %[vx]\n\t"                        // 10 C2  f_u[j] * V_x[j]
+        "v_add_f32_dpp %[pu], %[t], %[t] row_ror:12" DPPT             // 11 B   pu done (down the rows; column form)
+        "v_add_f32_dpp %[pr], %[t2], %[t2] quad_perm:[2,3,0,1]" DPPT  // 12 R   pr done (along the row; row form)
+        "v_fmac_f32_dpp %[qx], %[vx], %[sj2] quad_perm:[2,3,0,1]" DPPT  // 13 C
+        "v_fmac_f32_dpp %[P], %[V], %[si3] row_ror:4" DPPT            // 14 A   P done
+        "v_fma_f32 %[Qux], %[sj0], %[pu], %[vj2]\n\t"               // 15 B   Q_ux[j] = l_ux[j] + ...
+        "v_fma_f32 %[Quxi], %[si0], %[pr], %[luxi]\n\t"             // 16 R   Q_ux[i] = l_ux[i] + ...
+        "v_fmac_f32_dpp %[qx], %[vx], %[sj3] quad_perm:[3,0,1,2]" DPPT  // 17 C   Q_x done
+        "v_fmac_f32 %[qu], %[m0], %[vj3]\n\t"                       // 18 C2  + l_u on lane j = 0
+        "v_fma_f32 %[Qxx], %[sj0], %[P], %[lxx]\n\t"                // 19 A   Q_xx = l_xx + ...
+        "v_mul_f32 %[quu], %[pu], %[vj0]\n\t"                       // 20 B2  pu[j] * f_u[j]
+        "v_fmac_f32_dpp %[Qux], %[pu], %[sj1] quad_perm:[1,2,3,0]" DPPT  // 21 B
+        "v_fmac_f32_dpp %[Quxi], %[pr], %[si1] row_ror:12" DPPT       // 22 R
+        "v_fmac_f32_dpp %[Qxx], %[P], %[sj1] quad_perm:[1,2,3,0]" DPPT  // 23 A
+        "v_fmac_f32 %[quu], %[m1], %[vj3]\n\t"                      // 24 B2  + l_uu on lane j = 1
+        "v_add_f32_dpp %[t], %[qu], %[qu] quad_perm:[1,0,3,2]" DPPT   // 25 C2
+        "v_fmac_f32_dpp %[Qux], %[pu], %[sj2] quad_perm:[2,3,0,1]" DPPT  // 26 B
+        "v_fmac_f32_dpp %[Quxi], %[pr], %[si2] row_ror:8" DPPT        // 27 R
+        "v_fmac_f32_dpp %[Qxx], %[P], %[sj2] quad_perm:[2,3,0,1]" DPPT  // 28 A
+        "v_add_f32_dpp %[t2], %[quu], %[quu] quad_perm:[1,0,3,2]" DPPT  // 29 B2
+        "v_add_f32_dpp %[qu], %[t], %[t] quad_perm:[2,3,0,1]" DPPT    // 30 C2  Q_u done
+        "v_fmac_f32_dpp %[Qux], %[pu], %[sj3] quad_perm:[3,0,1,2]" DPPT  // 31 B   Q_ux (column form) done
+        "v_fmac_f32_dpp %[Quxi], %[pr], %[si3] row_ror:4" DPPT        // 32 R   Q_ux (row form) done
+        "v_fmac_f32_dpp %[Qxx], %[P], %[sj3] quad_perm:[3,0,1,2]" DPPT  // 33 A   Q_xx done
+        "v_add_f32_dpp %[quu], %[t2], %[t2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"  // 34 B2 Q_uu done
+        : [P] "=&v"(P), [pu] "=&v"(pu), [pr] "=&v"(pr), [qx] "=&v"(qx), [qu] "=&v"(qu), [quu] "=&v"(quu),
+          [Qxx] "=&v"(Qxx), [Qux] "=&v"(Qux), [Quxi] "=&v"(Quxi), [t] "=&v"(t), [t2] "=&v"(t2)
+        : [V] "v"(V), [vx] "v"(vx), [si0] "v"(c.ski[0]), [si1] "v"(c.ski[1]), [si2] "v"(c.ski[2]), [si3] "v"(c.ski[3]),
+          [sj0] "v"(c.skj[0]), [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]), [sj3] "v"(c.skj[3]), [vj0] "v"(c.vj[0]),
+          [vj1] "v"(c.vj[1]), [vj2] "v"(c.vj[2]), [vj3] "v"(c.vj[3]), [lxx] "v"(c.lxx), [bi] "v"(c.bi),
+          [luxi] "v"(c.luxi), [m0] "v"(lc.m0), [m1] "v"(lc.m1));
+#undef DPPT
     pd = quu > 0.0f;
-    // Q_ux in row form (lane (i, j) <- Q_ux[i]) through the LDS crossbar.  (Four bank-masked DPP moves do
-    // the same with less latency but three more issue slots: measured 38.3 vs 36.6 us per workgroup.)
     const float inv = fast_rcp(quu);
-    const float Quxi = lane_transpose(Qux, lc.tr_byte);
     Kj = -(Qux * inv);
     kff = -(qu * inv);
     V = fmaf(Quxi, Kj, Qxx);
@@ -463,8 +489,12 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     off.vi = (int)((b * kTile16 + 4 * i) * sizeof(T));
     off.vj = (int)((b * kTile16 + 4 * j) * sizeof(T));
     off.vl = (int)((b * kTile16 + l16) * sizeof(T));
-    const int rec_off = (int)((b * R + (i == 0 ? j : 4)) * sizeof(T));
+    // lanes (0, j) store K[j], lane (1, 0) stores k.  fp32: every other lane's offset lies beyond the descriptor's
+    // range, where the hardware drops the store -- no exec-mask juggling around the one counted store of a step.
+    // (The same trick on the 64-bit store of the fp64 sweep produced wrong gains; it keeps the predicate.)
+    constexpr bool DROP = sizeof(T) == 4;
     const bool storer = act && (i == 0 || l16 == 4);
+    const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : 4)) * sizeof(T)) : 0x7ffffff0;
     bool all_pd = true;
     LaneConst<T> lc;
     lc.m0 = T(j == 0);
@@ -477,7 +507,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
         if constexpr (sizeof(T) == 4 && !REG) tile16_step_f32(c, lc, V, vx, Kj, kff, pd);
         else tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
         all_pd = all_pd && pd;
-        if (storer) buf_store1(rgain, rec_off, uniform(t * rstride), (i == 0) ? Kj : kff);
+        if (DROP || storer) buf_store1(rgain, rec_off, uniform(t * rstride), (i == 0) ? Kj : kff);
     };
 
     int t = N - 1;
@@ -570,6 +600,7 @@ template <typename T> ILQR_DEV void tile16_load_lds(Tile16<T>& tl, const T* tp, 
     tl.vj[0] = v.x; tl.vj[1] = v.y; tl.vj[2] = v.z; tl.vj[3] = v.w;
     tl.lxx = tp[16 + l16];
     tl.bi = tp[32 + 4 * i];
+    tl.luxi = tp[32 + 4 * i + 2];
 }
 
 template <typename T, bool REG>

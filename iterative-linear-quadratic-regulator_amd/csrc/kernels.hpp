@@ -660,9 +660,12 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     // hardware drops the store (no exec-mask juggling around the counted stores)
     // (the same descriptors serve the ring's asm loads: one set of SGPRs)
     const __amdgpu_buffer_rsrc_t rXc = make_rsrc(a.X, bytesX), rUc = make_rsrc(a.U, bytesU);
+    // (32-bit stores only: the same trick on the 64-bit stores of the fp64 kernels wrote wrong data in the sweep,
+    // so fp64 keeps the exec-mask predicate)
+    constexpr bool DROP = sizeof(T) == 4;
     const int kDropped = 0x7ffffff0;
-    const int vXc = live ? (int)(((size_t)cslot * (N + 1) * NX * B + bb) * sizeof(T)) : kDropped;
-    const int vUc = live ? (int)(((size_t)cslot * N * NU * B + bb) * sizeof(T)) : kDropped;
+    const int vXc = (live || !DROP) ? (int)(((size_t)cslot * (N + 1) * NX * B + bb) * sizeof(T)) : kDropped;
+    const int vUc = (live || !DROP) ? (int)(((size_t)cslot * N * NU * B + bb) * sizeof(T)) : kDropped;
     const __amdgpu_buffer_rsrc_t srdG = make_rsrc(a.gains, (unsigned)((size_t)N * B * R * sizeof(T)));
     const int vx = (int)(((size_t)slot * (N + 1) * NX * B + bb) * sizeof(T));
     const int vu = (int)(((size_t)slot * N * NU * B + bb) * sizeof(T));
@@ -681,9 +684,11 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
         }
         // exactly NX + NU stores per step for every wave that is still running (they are counted)
 #pragma unroll
-        for (int i = 0; i < NX; ++i) buf_store1(rXc, vXc, uniform((t * NX + i) * rowB), x[i]);
+        for (int i = 0; i < NX; ++i)
+            if (DROP || live) buf_store1(rXc, vXc, uniform((t * NX + i) * rowB), x[i]);
 #pragma unroll
-        for (int j = 0; j < NU; ++j) buf_store1(rUc, vUc, uniform((t * NU + j) * rowB), u[j]);
+        for (int j = 0; j < NU; ++j)
+            if (DROP || live) buf_store1(rUc, vUc, uniform((t * NU + j) * rowB), u[j]);
         cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
         T xn[NX];
         Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);

@@ -452,3 +452,28 @@ def test_tensor_sweep_reproduces_the_system_sweep():
     uff2, K2 = h.backward_tensors(lin, term)
     np.testing.assert_array_equal(K2, K)
     np.testing.assert_array_equal(uff2, uff)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batch_members_do_not_see_each_other(dtype):
+    """A trajectory solved inside a ragged batch (dead lanes in the last wave, members that stop early and freeze while
+    the others go on) ends bit-identical to the same trajectory solved alone: nothing a dead or finished lane does --
+    dropped out-of-range stores, predicated stores, the slot moves of the linearisation -- leaks into its neighbours."""
+    N, B = 41, 67
+    p = problems.ua_double_pendulum(N=N)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], dtype)
+    x0, U0 = problems.ua_batch(B, seed=3, restarts=True, N=N)
+    x0 = x0 * np.linspace(0.0, 2.0, B)[:, None]
+    s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=0.3, maxiter=12, verbose=False)
+    X, U, cost = s.optimize_trajectory()
+    K, uff, it = s.K, s.U_ff, np.asarray(s.iterations)
+    assert it.min() < it.max()
+    for b in (0, 1, 31, 63, 64, 66):
+        one = ilqr_amd.iLQR(sysm, None, x0[b:b + 1], U0[b:b + 1], N=N, tol=0.3, maxiter=12, verbose=False)
+        X1, U1, c1 = one.optimize_trajectory()
+        assert int(one.iterations[0]) == int(it[b]) and one.status[0] == s.status[b]
+        np.testing.assert_array_equal(X[b], X1[0])
+        np.testing.assert_array_equal(U[b], U1[0])
+        np.testing.assert_array_equal(K[b], one.K[0])
+        np.testing.assert_array_equal(uff[b], one.U_ff[0])
+        np.testing.assert_array_equal(cost[b], c1[0])
