@@ -71,11 +71,13 @@ template <> struct M<float> {
         const f2 s = fma2(r * z, ps, r);
         const f2 pc = fma2(fma2(fma2(fma2(splat(kC4), z, splat(kC3)), z, splat(kC2)), z, splat(kC1)), z, splat(kC0));
         const f2 c = fma2(z, pc, splat(1.0f));
-        const unsigned g0 = __float_as_uint(t.x) << 31, g1 = __float_as_uint(t.y) << 31;
-        *s0 = __uint_as_float(__float_as_uint(s.x) ^ g0);
-        *c0 = __uint_as_float(__float_as_uint(c.x) ^ g0);
-        *s1 = __uint_as_float(__float_as_uint(s.y) ^ g1);
-        *c1 = __uint_as_float(__float_as_uint(c.y) ^ g1);
+        // (-1)^n as a float pair, applied with two packed multiplies (exact): 4 instructions for the four signs
+        // instead of 2 shifts + 4 xors
+        f2 sg;
+        sg.x = __uint_as_float((__float_as_uint(t.x) << 31) | 0x3f800000u);
+        sg.y = __uint_as_float((__float_as_uint(t.y) << 31) | 0x3f800000u);
+        const f2 ss = s * sg, cc = c * sg;
+        *s0 = ss.x; *c0 = cc.x; *s1 = ss.y; *c1 = cc.y;
     }
 };
 template <> struct M<double> {

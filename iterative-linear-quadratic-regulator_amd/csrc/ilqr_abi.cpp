@@ -231,6 +231,11 @@ int ilqr_debug_probe_dump(ilqr_handle h, long long* dst, size_t n) {
     if (!h || !h->impl) return ILQR_ERR_INVALID_ARG;
     return h->impl->probe_dump(dst, n);
 }
+/* diagnostic (not in the public header): retarget the handle's launches to another stream (tools/cumask_probe.py) */
+int ilqr_debug_set_stream(ilqr_handle h, void* stream) {
+    if (!h || !h->impl) return ILQR_ERR_INVALID_ARG;
+    return h->impl->debug_set_stream(stream);
+}
 int ilqr_timing_enable(ilqr_handle h, int on) { ILQR_FWD(h, timing_enable(on)); }
 int ilqr_timing_reset(ilqr_handle h) { ILQR_FWD(h, timing_reset()); }
 int ilqr_timing_get(ilqr_handle h, double ms[ILQR_N_PHASES], int64_t launches[ILQR_N_PHASES]) {

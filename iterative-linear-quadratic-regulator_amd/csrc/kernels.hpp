@@ -98,7 +98,11 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     const int b = (int)(idx % B);
     const bool inr = t <= a.N;                                  // a (b, t) point of the batch
     const bool live = inr && traj_active(a.status[b]);
-    const T* __restrict__ p = a.params;
+    // the parameter block is read before the kernel's first store: hipcc then uses scalar loads (SGPRs); reads
+    // that follow a store it cannot disambiguate become per-lane vector loads with their own vmcnt waits
+    T p[PL::TOTAL];
+#pragma unroll
+    for (int q = 0; q < PL::TOTAL; ++q) p[q] = a.params[q];
     T x[NX], u[NU];
     // Canonicalisation: accepting a candidate only moves cur_slot[b] (no copy), so after a few iterations
     // neighbouring trajectories live in different slots and every wave-wide access of the rollout -- 64

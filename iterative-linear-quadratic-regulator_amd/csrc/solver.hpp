@@ -46,6 +46,7 @@ struct SolverBase {
     virtual int mpc_run(int n_steps, void* u_out, void* x_out, void* cost_out) = 0;
     virtual int status_reduce(void* dev_out4) = 0;
     virtual int probe_dump(long long* dst, size_t n) = 0;
+    virtual int debug_set_stream(void* s) = 0;   // experiments only (tools/cumask_probe.py)
     virtual int timing_enable(int on) = 0;
     virtual int timing_reset() = 0;
     virtual int timing_get(double* ms, int64_t* launches) = 0;
@@ -948,6 +949,7 @@ template <typename T> class SolverT : public SolverBase {
         return sync();
     }
 
+    int debug_set_stream(void* sp) override { stream = (hipStream_t)sp; return ILQR_OK; }
     int probe_dump(long long* dst, size_t n) override {
         if (!dst || n > probe_elems) { err = "probe_dump: bad size"; return ILQR_ERR_INVALID_ARG; }
         ILQR_HIPCHK(hipMemcpyAsync(dst, probe, n * sizeof(long long), hipMemcpyDeviceToHost, stream));
