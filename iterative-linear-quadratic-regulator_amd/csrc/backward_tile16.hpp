@@ -457,11 +457,14 @@ ILQR_DEV void tile16_step_f32(const Tile16<float>& c, const LaneConst<float>& lc
 // the slowest wave is the kernel's duration.)
 constexpr int kTile16PinLds = 84 * 1024;
 
-template <typename T, bool REG>
+// NXA = the system's real n_x (2..4): smaller systems ride the same 4 x 4 tile, zero-padded by linearize_kernel
+// (padding states have no dynamics and no cost: their gains come out exactly zero and nothing else changes);
+// only the gain record (gain_record(NXA, 1) scalars: K[0..NXA), k) knows the difference.
+template <typename T, bool REG, int NXA>
 __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     // tiles in flight per lane: (D-1) * (loads per tile + 1 store) must stay <= 63 (the vmcnt field)
     constexpr int D = sizeof(T) == 4 ? 10 : 7;
-    constexpr int R = gain_record(4, 1);       // 8
+    constexpr int R = gain_record(NXA, 1);     // 8 for n_x = 4
     const int lane = threadIdx.x & 63;
     const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
     const int gidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
@@ -493,8 +496,8 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     // range, where the hardware drops the store -- no exec-mask juggling around the one counted store of a step.
     // (The same trick on the 64-bit store of the fp64 sweep produced wrong gains; it keeps the predicate.)
     constexpr bool DROP = sizeof(T) == 4;
-    const bool storer = act && (i == 0 || l16 == 4);
-    const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : 4)) * sizeof(T)) : 0x7ffffff0;
+    const bool storer = act && ((i == 0 && j < NXA) || l16 == 4);
+    const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : NXA)) * sizeof(T)) : 0x7ffffff0;
     bool all_pd = true;
     LaneConst<T> lc;
     lc.m0 = T(j == 0);
@@ -603,10 +606,10 @@ template <typename T> ILQR_DEV void tile16_load_lds(Tile16<T>& tl, const T* tp, 
     tl.luxi = tp[32 + 4 * i + 2];
 }
 
-template <typename T, bool REG>
+template <typename T, bool REG, int NXA>
 __global__ void __launch_bounds__(64) backward_tile16_lds_kernel(KArgs<T> a) {
     constexpr int RING = LdsRing<T>::RING, NDMA = LdsRing<T>::NDMA;
-    constexpr int R = gain_record(4, 1);
+    constexpr int R = gain_record(NXA, 1);
     constexpr int SLOT = 4 * kTile16;                    // scalars per ring slot (4 trajectories)
     constexpr int SLOT_BYTES = SLOT * (int)sizeof(T);    // 768 / 1536
     constexpr int PIECES = SLOT_BYTES / 16;              // 16-B pieces per slot: 48 / 96
@@ -626,8 +629,8 @@ __global__ void __launch_bounds__(64) backward_tile16_lds_kernel(KArgs<T> a) {
     const int N = a.N;
     T V = a.term[(size_t)(4 + l16) * B + b];
     T vx = a.term[(size_t)j * B + b];
-    T* __restrict__ rec = a.gains + (size_t)b * R + (i == 0 ? j : 4);
-    const bool storer = act && (i == 0 || l16 == 4);
+    T* __restrict__ rec = a.gains + (size_t)b * R + (i == 0 ? j : NXA);
+    const bool storer = act && ((i == 0 && j < NXA) || l16 == 4);
     const size_t rstride = B * R;
     bool all_pd = true;
 
@@ -695,36 +698,45 @@ __global__ void __launch_bounds__(64) backward_tile16_lds_kernel(KArgs<T> a) {
     if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
 }
 
-// dense ILQR_LIN order from a tile (debug / tests): e in [0, 46)
-ILQR_DEV int tile16_index_of(int e) {
-    if (e < 16) { const int i = e >> 2, j = e & 3; return 4 * j + ((i - j + 4) & 3); }  // f_x[i][j]
-    if (e < 20) return 32 + 4 * (e - 16);           // f_u[i]
-    if (e < 24) return 32 + 4 * (e - 20) + 1;       // l_x[i]
-    if (e == 24) return 35;                          // l_u
-    if (e < 41) return 16 + (e - 25);                // l_xx
-    if (e < 45) return 32 + 4 * (e - 41) + 2;       // l_ux[j]
+// position in the 48-scalar tile of entry e of the dense ILQR_LIN record of an (n, 1) system, n <= 4:
+// record = [f_x n*n | f_u n | l_x n | l_u | l_xx n*n | l_ux n | l_uu]
+ILQR_DEV int tile16_index_of(int e, int n) {
+    const int nn = n * n;
+    if (e < nn) { const int i = e / n, j = e % n; return 4 * j + ((i - j + 4) & 3); }   // f_x[i][j]
+    e -= nn;
+    if (e < n) return 32 + 4 * e;                    // f_u[i]
+    e -= n;
+    if (e < n) return 32 + 4 * e + 1;                // l_x[i]
+    e -= n;
+    if (e == 0) return 35;                           // l_u
+    e -= 1;
+    if (e < nn) return 16 + 4 * (e / n) + (e % n);   // l_xx[i][j]
+    e -= nn;
+    if (e < n) return 32 + 4 * e + 2;                // l_ux[j]
     return 39;                                       // l_uu
 }
 
 template <typename T>
-__global__ void tile16_gather_dense_kernel(T* dense, const T* lin, int B, int N) {
+__global__ void tile16_gather_dense_kernel(T* dense, const T* lin, int B, int N, int n) {
+    const int E = 2 * n * n + 3 * n + 2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * N * 46) return;
-    const int e = (int)(idx % 46);
-    const int t = (int)((idx / 46) % N);
-    const int b = (int)(idx / ((size_t)46 * N));
-    dense[idx] = lin[((size_t)t * B + b) * kTile16 + tile16_index_of(e)];
+    if (idx >= (size_t)B * N * E) return;
+    const int e = (int)(idx % E);
+    const int t = (int)((idx / E) % N);
+    const int b = (int)(idx / ((size_t)E * N));
+    dense[idx] = lin[((size_t)t * B + b) * kTile16 + tile16_index_of(e, n)];
 }
 
-// inverse: dense ILQR_LIN records -> tiles (the two pad scalars of a tile are zeroed by the caller's memset)
+// inverse: dense ILQR_LIN records -> tiles (pad scalars and the padding rows / columns are zeroed by the caller's memset)
 template <typename T>
-__global__ void tile16_scatter_dense_kernel(const T* dense, T* lin, int B, int N) {
+__global__ void tile16_scatter_dense_kernel(const T* dense, T* lin, int B, int N, int n) {
+    const int E = 2 * n * n + 3 * n + 2;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)B * N * 46) return;
-    const int e = (int)(idx % 46);
-    const int t = (int)((idx / 46) % N);
-    const int b = (int)(idx / ((size_t)46 * N));
-    lin[((size_t)t * B + b) * kTile16 + tile16_index_of(e)] = dense[idx];
+    if (idx >= (size_t)B * N * E) return;
+    const int e = (int)(idx % E);
+    const int t = (int)((idx / E) % N);
+    const int b = (int)(idx / ((size_t)E * N));
+    lin[((size_t)t * B + b) * kTile16 + tile16_index_of(e, n)] = dense[idx];
 }
 
 }  // namespace ilqr

@@ -150,11 +150,20 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
         T g[NX], H[NX][NX];
         Cost<T, Dyn>::l_f_x(p, x, g);
         Cost<T, Dyn>::l_f_xx(p, x, H);
+        if constexpr (TILE16) {
+            // the DPP sweep reads the terminal expansion on its 4 x 4 tile: [V_x (4) | V_xx (4 x 4)], zero-padded
 #pragma unroll
-        for (int i = 0; i < NX; ++i) a.term[(size_t)i * B + b] = g[i];
+            for (int i = 0; i < 4; ++i) a.term[(size_t)i * B + b] = i < NX ? g[i < NX ? i : 0] : T(0);
 #pragma unroll
-        for (int i = 0; i < NX * NX; ++i) a.term[(size_t)(NX + i) * B + b] = H[i / NX][i % NX];
-        if constexpr (!TILE16) return;
+            for (int i = 0; i < 16; ++i)
+                a.term[(size_t)(4 + i) * B + b] = (i / 4 < NX && i % 4 < NX) ? H[i / 4 < NX ? i / 4 : 0][i % 4 < NX ? i % 4 : 0] : T(0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) a.term[(size_t)i * B + b] = g[i];
+#pragma unroll
+            for (int i = 0; i < NX * NX; ++i) a.term[(size_t)(NX + i) * B + b] = H[i / NX][i % NX];
+            return;
+        }
     }
     const bool point = live && t < a.N;   // this lane produces an expansion record
     T xn[NX], fx[NX][NX], fu[NX][NU];
@@ -165,25 +174,31 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
         // lane holds ITS tile: a direct store would be 12 x 16-B pieces at a 192/384-B lane stride
         // (measured 1.34x write amplification).  So the wave transposes through LDS in chunks and writes
         // 16 B per lane to consecutive addresses.
-        static_assert(NX == 4 && NU == 1, "tile packing is for n_x = 4, n_u = 1");
+        static_assert(NX >= 2 && NX <= 4 && NU == 1, "tile packing is for n_x <= 4, n_u = 1");
         using V4 = typename Vec4<T>::type;
-        T gx[NX], gu1[NU], lxx[NX][NX], lux[NU][NX], luu[NU][NU];
-        Cost<T, Dyn>::grad(p, a.dt, x, u, gx, gu1);
-        Cost<T, Dyn>::hess(p, a.dt, x, u, lxx, lux, luu);
+        T gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
+        Cost<T, Dyn>::grad(p, a.dt, x, u, gxn, gu1);
+        Cost<T, Dyn>::hess(p, a.dt, x, u, lxxn, luxn, luu);
+        // zero-pad to the 4 x 4 tile (a no-op for n_x = 4): padding states have no dynamics and no cost
+        auto F = [&](int i, int j) -> T { return (i < NX && j < NX) ? fx[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
+        auto L = [&](int i, int j) -> T { return (i < NX && j < NX) ? lxxn[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
         V4 tile[12];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            tile[c].x = fx[(c + 0) & 3][c]; tile[c].y = fx[(c + 1) & 3][c];
-            tile[c].z = fx[(c + 2) & 3][c]; tile[c].w = fx[(c + 3) & 3][c];
+            tile[c].x = F((c + 0) & 3, c); tile[c].y = F((c + 1) & 3, c);
+            tile[c].z = F((c + 2) & 3, c); tile[c].w = F((c + 3) & 3, c);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            tile[4 + i].x = lxx[i][0]; tile[4 + i].y = lxx[i][1];
-            tile[4 + i].z = lxx[i][2]; tile[4 + i].w = lxx[i][3];
+            tile[4 + i].x = L(i, 0); tile[4 + i].y = L(i, 1);
+            tile[4 + i].z = L(i, 2); tile[4 + i].w = L(i, 3);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tile[8 + j].x = fu[j][0]; tile[8 + j].y = gx[j]; tile[8 + j].z = lux[0][j];
+            const int jj = j < NX ? j : 0;
+            tile[8 + j].x = j < NX ? fu[jj][0] : T(0);
+            tile[8 + j].y = j < NX ? gxn[jj] : T(0);
+            tile[8 + j].z = j < NX ? luxn[0][jj] : T(0);
             tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
         }
         // passes over groups of whole tiles (so every pass writes one contiguous run of full cache lines):

@@ -138,7 +138,7 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
 template <typename T, typename Dyn> Ops<T> make_ops() {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     Ops<T> o;
-    constexpr bool TILE = (NX == 4 && NU == 1);
+    constexpr bool TILE = (NU == 1 && NX >= 2 && NX <= 4);   // the DPP sweep; n_x < 4 rides the 4 x 4 tile zero-padded
     o.tile16 = TILE;
     o.canonical = true;
     o.lin_stride = TILE ? kTile16 : (2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU);
@@ -155,23 +155,23 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
             const bool fits = (size_t)a.N * a.B * kTile16 * sizeof(T) < (1ull << 31);
             if (lds_ring || !fits) {
                 const dim3 grid((a.B + 3) / 4), block(64);
-                if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16_lds_kernel<T, true>), grid, block, 0, s, a);
-                else ILQR_LAUNCH((backward_tile16_lds_kernel<T, false>), grid, block, 0, s, a);
+                if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16_lds_kernel<T, true, NX>), grid, block, 0, s, a);
+                else ILQR_LAUNCH((backward_tile16_lds_kernel<T, false, NX>), grid, block, 0, s, a);
                 return;
             }
             // 16 trajectories per 256-thread workgroup, one workgroup per CU (see kTile16PinLds)
             static const bool pinned = [] {
-                bool ok = hipFuncSetAttribute((const void*)backward_tile16_kernel<T, false>,
+                bool ok = hipFuncSetAttribute((const void*)backward_tile16_kernel<T, false, NX>,
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTile16PinLds) == hipSuccess;
-                ok = ok && hipFuncSetAttribute((const void*)backward_tile16_kernel<T, true>,
+                ok = ok && hipFuncSetAttribute((const void*)backward_tile16_kernel<T, true, NX>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, kTile16PinLds) == hipSuccess;
                 (void)hipGetLastError();
                 return ok && getenv("ILQR_BACKWARD_NO_PIN") == nullptr;
             }();
             const dim3 grid((a.B + 15) / 16), block(256);
             const size_t lds = pinned ? kTile16PinLds : 0;
-            if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16_kernel<T, true>), grid, block, lds, s, a);
-            else ILQR_LAUNCH((backward_tile16_kernel<T, false>), grid, block, lds, s, a);
+            if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16_kernel<T, true, NX>), grid, block, lds, s, a);
+            else ILQR_LAUNCH((backward_tile16_kernel<T, false, NX>), grid, block, lds, s, a);
         };
     } else {
         o.backward = [](const KArgs<T>& a, hipStream_t s) {
@@ -392,7 +392,7 @@ template <typename T> class SolverT : public SolverBase {
         ILQR_HIPCHK(al(&s.U, (size_t)n_slots * N * NU * b));
         ILQR_HIPCHK(al(&s.gains, (size_t)N * R * b));
         ILQR_HIPCHK(al(&s.lin, (size_t)N * ops.lin_stride * b));
-        ILQR_HIPCHK(al(&s.term, (size_t)(NX + NX * NX) * b));
+        ILQR_HIPCHK(al(&s.term, (size_t)(ops.tile16 ? 20 : NX + NX * NX) * b));   // tile mode: padded to 4 + 4 x 4
         ILQR_HIPCHK(al(&s.x0, (size_t)NX * b));
         ILQR_HIPCHK(al(&s.costs, (size_t)kMaxAlpha * b));
         ILQR_HIPCHK(al(&s.cost, b));
@@ -545,7 +545,7 @@ template <typename T> class SolverT : public SolverBase {
         }
         if (!ops.tile16) return down_tc(host, lin, E, N);
         const size_t n = (size_t)B * N * E;
-        hipLaunchKernelGGL(tile16_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
+        hipLaunchKernelGGL(tile16_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, NX);
         ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
         return check_launch();
@@ -563,7 +563,7 @@ template <typename T> class SolverT : public SolverBase {
         if (!ops.tile16) return up_tc(host, lin, E, N);
         ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
         ILQR_HIPCHK(hipMemsetAsync(lin, 0, (size_t)N * B * kTile16 * sizeof(T), stream));
-        hipLaunchKernelGGL(tile16_scatter_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
+        hipLaunchKernelGGL(tile16_scatter_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, NX);
         ILQR_HIPCHK(hipStreamSynchronize(stream));
         return check_launch();
     }
@@ -869,7 +869,19 @@ template <typename T> class SolverT : public SolverBase {
         int rc;
         if ((rc = ensure_fn()) || (rc = reset_fn())) return rc;
         if ((rc = up_lin(lin, fn.lin))) return rc;
-        if ((rc = up_tc(term, fn.term, NX + NX * NX, 1))) return rc;
+        if (ops.tile16 && NX < 4) {
+            // the sweep reads [V_x (4) | V_xx (4 x 4)] zero-padded
+            std::vector<T> pad((size_t)B * 20, T(0));
+            const T* src = (const T*)term;
+            for (int bq = 0; bq < B; ++bq) {
+                for (int i = 0; i < NX; ++i) pad[(size_t)bq * 20 + i] = src[(size_t)bq * (NX + NX * NX) + i];
+                for (int i = 0; i < NX; ++i)
+                    for (int j = 0; j < NX; ++j) pad[(size_t)bq * 20 + 4 + 4 * i + j] = src[(size_t)bq * (NX + NX * NX) + NX + i * NX + j];
+            }
+            if ((rc = up_tc(pad.data(), fn.term, 20, 1))) return rc;
+        } else if ((rc = up_tc(term, fn.term, NX + NX * NX, 1))) {
+            return rc;
+        }
         if ((rc = do_backward(fn))) return rc;
         if (Uff && (rc = down_gain_k(Uff, fn.gains))) return rc;
         if (K && (rc = down_gain_K(K, fn.gains))) return rc;
