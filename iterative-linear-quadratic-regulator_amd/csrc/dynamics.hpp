@@ -128,6 +128,19 @@ ILQR_DEV double fast_rcp(double x) {
     return fma(fma(-x, r, 1.0), r, r);
 }
 
+// reciprocal square root = hardware estimate + Newton steps (1 for float, 2 for double): ~1 ulp; the Cholesky of the
+// wave sweep takes L_cc = d * rsqrt(d) and 1 / L_cc = rsqrt(d) from it instead of an IEEE sqrt and an IEEE division
+// per column on the step's serial chain
+ILQR_DEV float fast_rsqrt(float x) {
+    float r = __builtin_amdgcn_rsqf(x);
+    return r * fmaf(-0.5f * x, r * r, 1.5f);
+}
+ILQR_DEV double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x, r * r, 1.5);
+    return r * fma(-0.5 * x, r * r, 1.5);
+}
+
 // ---------------------------------------------------------------------------
 // Device parameter block (scalars of type T, built on the host in double by
 // build_device_params() in ilqr_abi.hip):

@@ -295,7 +295,8 @@ __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
         lds_matmul<T, NU, NX, NU, false>(Pu, fu, Quu, lane, [&](int r, int c) { return tile[oLUU + r * NU + c]; });
         __syncthreads();
         // ---- phase 3: Cholesky of Q_uu + mu I, redundantly in every lane's registers (no barriers) -----------
-        T Lr[NU][NU];
+        T Lr[NU][NU], Li[NU];   // Li[c] = 1 / L[c][c]: the substitutions multiply by it (one division per column
+                                // instead of 2 * NU per right-hand side on the step's serial chain)
         bool pd = true;
 #pragma unroll
         for (int c = 0; c < NU; ++c) {
@@ -303,9 +304,10 @@ __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
 #pragma unroll
             for (int s2 = 0; s2 < c; ++s2) d -= Lr[c][s2] * Lr[c][s2];
             pd = pd && (d > T(0));
-            const T lcc = M<T>::sqrt(d);
+            const T inv = fast_rsqrt(pd ? d : T(1));   // (not positive definite: the LU branch below takes over)
+            const T lcc = d * inv;
             Lr[c][c] = lcc;
-            const T inv = T(1) / lcc;
+            Li[c] = inv;
 #pragma unroll
             for (int i2 = c + 1; i2 < NU; ++i2) {
                 T v = Quu[i2 * NU + c];
@@ -324,14 +326,14 @@ __global__ void __launch_bounds__(64) backward_wave_kernel(KArgs<T> a) {
                     T v = lane < NX ? Qux[i2 * NX + lane] : Qu[i2];
 #pragma unroll
                     for (int s2 = 0; s2 < i2; ++s2) v -= Lr[i2][s2] * y[s2];
-                    y[i2] = v / Lr[i2][i2];
+                    y[i2] = v * Li[i2];
                 }
 #pragma unroll
                 for (int i2 = NU - 1; i2 >= 0; --i2) {
                     T v = y[i2];
 #pragma unroll
                     for (int s2 = i2 + 1; s2 < NU; ++s2) v -= Lr[s2][i2] * y[s2];
-                    y[i2] = v / Lr[i2][i2];
+                    y[i2] = v * Li[i2];
                 }
 #pragma unroll
                 for (int i2 = 0; i2 < NU; ++i2) Z[i2 * NRHS + lane] = -y[i2];
