@@ -63,7 +63,7 @@ def _printer(n_x, n_u):
             b = self.parenthesize(base, 1000)
             if ex.is_Integer and 1 <= abs(int(ex)) <= 4:
                 prod = " * ".join([b] * abs(int(ex)))
-                return f"({prod})" if int(ex) > 0 else f"(T(1) / ({prod}))"
+                return f"({prod})" if int(ex) > 0 else f"um::rcp({prod})"
             if ex == sp_half():
                 return f"um::sqrt({self._print(base)})"
             if ex == -sp_half():
@@ -87,8 +87,38 @@ def _trace_symbols(n_x, n_u):
     pr._print_Symbol = lambda s: names.get(s, s.name)  # cse temporaries keep their own names
 
     def block(targets):
-        repl, red = sp.cse([e for _, e in targets], symbols=sp.numbered_symbols("w_"), optimizations="basic")
-        lines = [f"        const T {pr.doprint(s)} = {pr.doprint(e)};" for s, e in repl]
+        exprs = [e for _, e in targets]
+        # sin / cos of a SUM go through the addition theorems first (sin(q1 + q2) costs two multiply-adds once
+        # sin q1, cos q1, sin q2, cos q2 are there, against a third range reduction and polynomial pair)
+        sums = {f: sp.expand_trig(f) for e in exprs for f in e.atoms(sp.sin, sp.cos) if f.args[0].is_Add}
+        if sums:
+            exprs = [e.xreplace(sums) for e in exprs]
+        # sines and cosines whose argument depends on x, u only are hoisted and evaluated as sin/cos PAIRS, two
+        # angles per call (um::sincos2: one range reduction per angle, packed FP32 arithmetic for the two angles --
+        # what the hand-written systems do); anything more exotic stays a plain um::sin / um::cos call
+        args = []
+        for e in exprs:
+            for f in e.atoms(sp.sin, sp.cos):
+                a = f.args[0]
+                if a.free_symbols <= set(xs) | set(us) and not a.atoms(sp.sin, sp.cos) and a not in args:
+                    args.append(a)
+        args.sort(key=sp.default_sort_key)
+        trig = {}
+        for k, a in enumerate(args):
+            trig[sp.sin(a)] = sp.Symbol(f"sn_{k}", real=True)
+            trig[sp.cos(a)] = sp.Symbol(f"cs_{k}", real=True)
+        exprs = [e.xreplace(trig) for e in exprs]
+        lines = []
+        if args:
+            lines.append("        T " + ", ".join(f"sn_{k}, cs_{k}" for k in range(len(args))) + ";")
+            for k in range(0, len(args) - 1, 2):
+                lines.append(f"        um::sincos2({pr.doprint(args[k])}, {pr.doprint(args[k + 1])}, &sn_{k}, &cs_{k}, "
+                             f"&sn_{k + 1}, &cs_{k + 1});")
+            if len(args) % 2:
+                k = len(args) - 1
+                lines.append(f"        um::sincos({pr.doprint(args[k])}, &sn_{k}, &cs_{k});")
+        repl, red = sp.cse(exprs, symbols=sp.numbered_symbols("w_"), optimizations="basic")
+        lines += [f"        const T {pr.doprint(s)} = {pr.doprint(e)};" for s, e in repl]
         lines += [f"        {name} = {pr.doprint(e)};" for (name, _), e in zip(targets, red)]
         return "\n".join(lines)
 
