@@ -548,8 +548,6 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
                 // refill the SAME registers with the tile D steps ahead (clamped to tile 0 at the end of the
                 // sweep: the body stays branch-free; the surplus loads are drained before the kernel ends).
                 // (Issuing the refill in the middle of the NEXT step instead, inside its latency-bound tail,
-                // was tried: 43.8 vs 40.6 us -- the extra asm statement splits hipcc's schedule of the tail.).
-                // (Issuing the refill in the middle of the NEXT step instead, inside its latency-bound tail,
                 // was tried: 43.8 vs 40.6 us -- the extra asm statement splits hipcc's schedule of the tail.)
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
                 ring[u].issue(srd, off, uniform(tn * tstride));

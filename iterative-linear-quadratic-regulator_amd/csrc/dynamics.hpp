@@ -20,17 +20,15 @@ namespace ilqr {
 
 // Lean sin/cos pair, branch-free, both values from one reduction (the libm entry points carry a Payne-Hanek
 // slow path and a branch per call, which dominated the rollout's instruction stream).
-//   double: Cody-Waite reduction by pi/2 in three FMA steps, the fdlibm kernel polynomials on [-pi/4, pi/4]
-//           and a quadrant select; <= 1 ulp for |x| < 1e3.
-//   float:  reduction by pi (n from the 1.5*2^23 rounding constant, so no rndne / cvt), minimax polynomials
-//           on [-pi/2, pi/2], and ONE sign for both values (sin(r + n pi) = (-1)^n sin r, same for cos) taken
-//           straight from the low bit of the rounding constant's sum.  Reducing by pi/2 instead costs a
-//           quadrant select of ~11 integer / compare / select instructions per angle -- measured at 22 % of the
-//           RK4 rollout's instruction stream -- against two more FMAs here.  Absolute error <= 1.1e-7 (sin),
-//           1.5e-7 (cos) for |x| < 1e3 (checked against libm on the CPU with the same constants; the pi/2 form
-//           had 0.9e-7), graceful beyond -- pendulum angles never leave that range on a rollout whose cost is
-//           still finite.  sincos2 evaluates two angles in packed FP32 (v_pk_fma_f32: two lanes' worth of FMA
-//           per issue slot) with exactly the arithmetic of sincos, so both give bit-identical results.
+// Both precisions reduce by pi (n from the 1.5 * 2^23 / 1.5 * 2^52 rounding constant, so no rndne / cvt), evaluate
+// minimax polynomials on [-pi/2, pi/2], and apply ONE sign to both values (sin(r + n pi) = (-1)^n sin r, same for
+// cos) taken straight from the low bit of the rounding constant's sum.  Reducing by pi/2 instead costs a quadrant
+// select of ~11 integer / compare / select instructions per angle -- measured at 22 % of the fp32 RK4 rollout's
+// instruction stream -- against two to four more FMAs here.  Absolute error (checked on the CPU against libm /
+// 50-digit arithmetic with the same constants and operation order): float <= 1.1e-7 (sin), 1.5e-7 (cos); double
+// <= 2.1e-16, for |x| < 1e3, graceful beyond -- pendulum angles never leave that range on a rollout whose cost is
+// still finite.  The float sincos2 evaluates two angles in packed FP32 (v_pk_fma_f32: two lanes' worth of FMA per
+// issue slot) with exactly the arithmetic of sincos, so both give bit-identical results.
 template <typename T> struct M;
 template <> struct M<float> {
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -83,31 +81,40 @@ template <> struct M<float> {
 template <> struct M<double> {
     static ILQR_DEV double sqrt(double x) { return ::sqrt(x); }
     static ILQR_DEV double abs(double x) { return fabs(x); }
+    // same scheme as the float version: reduction by pi through the 1.5 * 2^52 rounding constant, near-minimax
+    // polynomials of degree 8 in r^2 on [-pi/2, pi/2] (Chebyshev-node fits computed with 40-digit arithmetic; error
+    // of the rounded polynomials 3.7e-17 / 1.6e-17), one sign for both values.  |error| <= ~1 ulp for |x| < 1e3.
     static ILQR_DEV void sincos(double x, double* sn, double* cs) {
-        const double n = rint(x * 0x1.45f306dc9c883p-1);
-        double r = fma(-n, 0x1.921fb54442d18p+0, x);
-        r = fma(-n, 0x1.1a62633145c07p-54, r);
-        r = fma(-n, -0x1.f1976b7ed8fbcp-110, r);
+        constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52
+        const double t = fma(x, 0x1.45f306dc9c883p-2, kMagic);
+        const double n = t - kMagic;
+        double r = fma(-n, 0x1.921fb54442d18p+1, x);
+        r = fma(-n, 0x1.1a62633145c07p-53, r);
+        r = fma(-n, -0x1.f1976b7ed8fbcp-109, r);
         const double z = r * r;
-        double ps = 1.58969099521155010221e-10;
-        ps = fma(ps, z, -2.50507602534068634195e-08);
-        ps = fma(ps, z, 2.75573137070700676789e-06);
-        ps = fma(ps, z, -1.98412698298579493134e-04);
-        ps = fma(ps, z, 8.33333333332248946124e-03);
-        ps = fma(ps, z, -1.66666666666666324348e-01);
+        double ps = -0x1.270e682f051a4p-57;
+        ps = fma(ps, z, 0x1.95050477e28a7p-49);
+        ps = fma(ps, z, -0x1.ae7ed8479c0cfp-41);
+        ps = fma(ps, z, 0x1.612460a028f3cp-33);
+        ps = fma(ps, z, -0x1.ae64567e422cdp-26);
+        ps = fma(ps, z, 0x1.71de3a556b61bp-19);
+        ps = fma(ps, z, -0x1.a01a01a01a009p-13);
+        ps = fma(ps, z, 0x1.1111111111111p-7);
+        ps = fma(ps, z, -0x1.5555555555555p-3);
         const double s = fma(r * z, ps, r);
-        double pc = -1.13596475577881948265e-11;
-        pc = fma(pc, z, 2.08757232129817482790e-09);
-        pc = fma(pc, z, -2.75573143513906633035e-07);
-        pc = fma(pc, z, 2.48015872894767294178e-05);
-        pc = fma(pc, z, -1.38888888888741095749e-03);
-        pc = fma(pc, z, 4.16666666666666019037e-02);
+        double pc = 0x1.d9462c98ff4d3p-62;
+        pc = fma(pc, z, -0x1.680acb0165568p-53);
+        pc = fma(pc, z, 0x1.ae7ef4057b587p-45);
+        pc = fma(pc, z, -0x1.93974a1b90fadp-37);
+        pc = fma(pc, z, 0x1.1eed8eff29abep-29);
+        pc = fma(pc, z, -0x1.27e4fb7789922p-22);
+        pc = fma(pc, z, 0x1.a01a01a01a014p-16);
+        pc = fma(pc, z, -0x1.6c16c16c16c17p-10);
+        pc = fma(pc, z, 0x1.5555555555555p-5);
         const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
-        const int q = (int)n;
-        const double a = (q & 1) ? c : s;
-        const double b = (q & 1) ? s : c;
-        *sn = (q & 2) ? -a : a;
-        *cs = ((q + 1) & 2) ? -b : b;
+        const int sign = __double2loint(t) << 31;       // parity of n
+        *sn = __hiloint2double(__double2hiint(s) ^ sign, __double2loint(s));
+        *cs = __hiloint2double(__double2hiint(c) ^ sign, __double2loint(c));
     }
     static ILQR_DEV void sincos2(double x0, double x1, double* s0, double* c0, double* s1, double* c1) {
         sincos(x0, s0, c0);
