@@ -23,7 +23,6 @@ import hashlib
 import os
 import shutil
 import subprocess
-import sys
 
 import numpy as np
 
@@ -34,6 +33,15 @@ PLUGIN_ROOT = os.path.join(_lib.HERE, "_plugins")
 TEMPLATE = os.path.join(_lib.CSRC, "plugin_template.hip.in")
 _KERNEL_HEADERS = ("dynamics.hpp", "kernels.hpp", "backward_tile16.hpp", "kernels_wave.hpp", "fwd_in_gen.inc",
                    "solver.hpp", "plugin_template.hip.in")
+
+
+def _ring_check():
+    """csrc/check_ring_kernels.py (shared with the library's Makefile), loaded by path."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ilqr_check_ring_kernels", os.path.join(_lib.CSRC, "check_ring_kernels.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def _printer(n_x, n_u):
@@ -203,11 +211,7 @@ def build_plugin(source, verbose=False):
     with open(hip, "w") as fh:
         fh.write(source)
     tmp = so + f".tmp{os.getpid()}"
-    sys.path.insert(0, _lib.CSRC)
-    try:
-        import check_ring_kernels as crk
-    finally:
-        sys.path.pop(0)
+    crk = _ring_check()
     base = [hipcc, "-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fvisibility=hidden",
             "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage", "-I", _lib.CSRC,
             "-I", os.path.join(_lib.HERE, "..", "include"), "-o", tmp, hip]
