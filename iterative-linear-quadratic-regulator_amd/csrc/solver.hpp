@@ -370,6 +370,7 @@ template <typename T> class SolverT : public SolverBase {
         hipFree(mpc_cost_log);
         if (h_counter) hipHostFree(h_counter);
         if (iter_graph) hipGraphExecDestroy(iter_graph);
+        if (loop_ev[0]) { hipEventDestroy(loop_ev[0]); hipEventDestroy(loop_ev[1]); }
         if (own_stream && stream) hipStreamDestroy(stream);
     }
 
@@ -814,17 +815,33 @@ template <typename T> class SolverT : public SolverBase {
     int run_solve_loop() {
         int rc;
         if ((rc = initial_rollout())) return rc;
+        if (!loop_ev[0]) {
+            ILQR_HIPCHK(hipEventCreateWithFlags(&loop_ev[0], hipEventDisableTiming));
+            ILQR_HIPCHK(hipEventCreateWithFlags(&loop_ev[1], hipEventDisableTiming));
+        }
+        // Inactive trajectories are skipped inside every kernel, so the only reason to look at the count of active
+        // ones is to stop launching once nobody is left.  The host reads it ONE ITERATION LATE: iteration i + 1 is
+        // already queued when it waits for the count of iteration i, so the stream never drains for the read-back
+        // (the price is one surplus iteration of early-exiting kernels at the end of a solve).
+        int prev = -1;
         for (int i = 0; i < cfg.maxiter; ++i) {
             int cidx;
             if ((rc = one_iteration(&cidx))) return rc;
-            // inactive trajectories are skipped inside every kernel, so the only reason to look
-            // at the count is to stop launching once nobody is left
             ILQR_HIPCHK(hipMemcpyAsync(h_counter + cidx, st.counters + cidx, sizeof(int), hipMemcpyDeviceToHost, stream));
-            ILQR_HIPCHK(hipStreamSynchronize(stream));
-            if (h_counter[cidx] == 0) break;
+            ILQR_HIPCHK(hipEventRecord(loop_ev[i & 1], stream));
+            static const bool eager = getenv("ILQR_SOLVE_SYNC_EVERY_ITERATION") != nullptr;   // A/B switch
+            if (eager) {
+                ILQR_HIPCHK(hipEventSynchronize(loop_ev[i & 1]));
+                if (h_counter[cidx] == 0) break;
+            } else if (prev >= 0) {
+                ILQR_HIPCHK(hipEventSynchronize(loop_ev[(i - 1) & 1]));
+                if (h_counter[prev] == 0) break;
+            }
+            prev = cidx;
         }
         return ILQR_OK;
     }
+    hipEvent_t loop_ev[2] = {nullptr, nullptr};
 
     int solve(int32_t* iters, void* cost) override {
         if (!have_problem) { err = "solve before set_problem"; return ILQR_ERR_STATE; }
