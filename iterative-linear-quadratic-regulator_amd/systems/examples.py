@@ -72,6 +72,18 @@ class Unicycle(SymbolicSystem):
         return [u[0] * sp.cos(x[2]), u[0] * sp.sin(x[2]), u[1]]
 
 
+class DubinsCar(SymbolicSystem):
+    """Constant-speed car; x = [px, py, heading], u = [turn rate] (n_x = 3, n_u = 1: rides the DPP sweep's 4 x 4 tile
+    zero-padded)."""
+
+    def __init__(self, dt, x_target, Q, R, Q_f, speed=1.0, **kw):
+        self.speed = float(speed)
+        super().__init__(3, 1, dt, x_target, Q, R, Q_f, **kw)
+
+    def _f_cont_fcn(self, x, u):
+        return [self.speed * sp.cos(x[2]), self.speed * sp.sin(x[2]), u[0]]
+
+
 class PlanarQuadrotor(SymbolicSystem):
     """Planar quadrotor; x = [px, pz, phi, vx, vz, phi_dot], u = [thrust_left, thrust_right] (n_x = 6, n_u = 2)."""
 
@@ -140,6 +152,8 @@ def example_problems(dtype=np.float64, integrator="rk4"):
                               np.diag([100.0, 100.0, 10.0, 10.0]), **kw), 80, np.array([0.0, 0.0, 0, 0])),
         "unicycle": (Unicycle(0.05, [1.0, 1.0, 0.5 * pi], np.diag([1.0, 1.0, 0.1]), np.diag([0.1, 0.1]),
                               np.diag([50.0, 50.0, 5.0]), **kw), 60, np.array([0.0, 0.0, 0.0])),
+        "dubins": (DubinsCar(0.05, [2.0, 1.0, 0.0], np.diag([0.5, 1.0, 0.2]), [[0.2]], np.diag([5.0, 50.0, 10.0]), **kw),
+                   60, np.array([0.0, 0.0, 0.2])),
         "quadrotor": (PlanarQuadrotor(0.02, [1.0, 1.0, 0, 0, 0, 0], np.diag([1.0, 1.0, 1.0, 0.1, 0.1, 0.1]),
                                       np.diag([0.1, 0.1]), np.diag([100.0, 100.0, 10.0, 10.0, 10.0, 1.0]), **kw),
                       50, np.array([0.0, 0.0, 0.0, 0, 0, 0])),

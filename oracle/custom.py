@@ -150,6 +150,10 @@ def unicycle_fc():
     return lambda x, u: np.array([u[0] * np.cos(x[2]), u[0] * np.sin(x[2]), u[1]])
 
 
+def dubins_fc(speed=1.0):
+    return lambda x, u: np.array([speed * np.cos(x[2]), speed * np.sin(x[2]), u[0]])
+
+
 def quadrotor_fc(mass=0.5, inertia=0.01, arm=0.2, g=9.81):
     def fc(x, u):
         phi = x[2]
@@ -195,7 +199,7 @@ def oracle_for_example(name, system, dtype=np.float64, integrator=None):
     cart = lambda: cartpole_fc(system.m_cart, system.m_pole, system.length, system.g)
     fc = {"sym_pendulum": lambda: pendulum_fc(system.g, system.l, system.d),
           "cartpole": cart, "swingup_cartpole": cart,
-          "unicycle": unicycle_fc, "obstacle_unicycle": unicycle_fc,
+          "unicycle": unicycle_fc, "obstacle_unicycle": unicycle_fc, "dubins": lambda: dubins_fc(system.speed),
           "quadrotor": lambda: quadrotor_fc(system.mass, system.inertia, system.arm, system.g)}[name]()
     if name == "swingup_cartpole":
         common["l"], common["l_f"] = swingup_costs(system.dt)

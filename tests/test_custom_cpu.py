@@ -13,7 +13,7 @@ from ilqr_amd.systems.custom_sys import generate_dyn_bodies
 from ilqr_amd.systems.examples import example_problems
 from oracle.custom import oracle_for_example
 
-NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "quadrotor", "swingup_cartpole", "obstacle_unicycle"]
+NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "dubins", "quadrotor", "swingup_cartpole", "obstacle_unicycle"]
 
 
 @pytest.mark.parametrize("name", NAMES)

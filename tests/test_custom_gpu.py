@@ -11,7 +11,7 @@ from oracle import backward_pass, forward_pass, iLQROracle, mpc_closed_loop
 from oracle.custom import oracle_for_example
 
 pytestmark = pytest.mark.gpu
-NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "quadrotor", "swingup_cartpole", "obstacle_unicycle"]
+NAMES = ["sym_pendulum", "sym_ua", "cartpole", "unicycle", "dubins", "quadrotor", "swingup_cartpole", "obstacle_unicycle"]
 RTOL = 1e-5
 
 
@@ -63,7 +63,7 @@ def test_custom_backward_and_forward_pass(name, dtype):
             _close(Xn[b], Xo, 1e-6 if dtype == np.float64 else 1e-4, f"{name} X")
 
 
-@pytest.mark.parametrize("name,maxiter", [("sym_pendulum", 15), ("cartpole", 10), ("unicycle", 12), ("quadrotor", 8),
+@pytest.mark.parametrize("name,maxiter", [("sym_pendulum", 15), ("cartpole", 10), ("unicycle", 12), ("dubins", 10), ("quadrotor", 8),
                                           ("swingup_cartpole", 10), ("obstacle_unicycle", 10)])
 def test_custom_full_solve(name, maxiter):
     """optimize_trajectory on a user system: same accepted alphas / iteration counts / status as the oracle."""
