@@ -171,6 +171,7 @@ template <int NSYS, int NX, int NU> struct ParamLayout {
 // ---- pendulum (pendulum_sys.py:60-75): derived constants [g/l, d] ------------
 template <typename T> struct Pendulum {
     static constexpr int NX = 2, NU = 1, NSYS = 2, ID = ILQR_SYS_PENDULUM;
+    static constexpr bool SECOND_ORDER = true;
     static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
         xd[0] = x[1];
         T s, c;
@@ -193,6 +194,7 @@ template <typename T> struct Pendulum {
 //                     c12 = m2 l2^2/4 + th2 (= m22), gA = m2 g l2/2, gB = (m2 + m1/2) g l1, d1, d2]
 template <typename T, int NU_> struct DoublePendulum {
     static constexpr int NX = 4, NU = NU_, NSYS = 7;
+    static constexpr bool SECOND_ORDER = true;
     static constexpr int ID = (NU_ == 1) ? ILQR_SYS_UA_DOUBLE_PENDULUM : ILQR_SYS_DOUBLE_PENDULUM;
 
     static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
@@ -351,6 +353,13 @@ template <typename Dyn> struct all_integrators<Dyn, decltype((void)Dyn::ALL_INTE
     static constexpr bool value = Dyn::ALL_INTEGRATORS;
 };
 
+// mechanical systems x = [q, q_dot] declare SECOND_ORDER: the chain rule through the integrator stages then skips the
+// trivial half of the continuous Jacobian (Stepper::stage)
+template <typename Dyn, typename = void> struct second_order { static constexpr bool value = false; };
+template <typename Dyn> struct second_order<Dyn, decltype((void)Dyn::SECOND_ORDER)> {
+    static constexpr bool value = Dyn::SECOND_ORDER && Dyn::NX % 2 == 0;
+};
+
 template <typename T, typename Dyn> struct Stepper {
     static constexpr int NX = Dyn::NX, NU = Dyn::NU;
     static constexpr bool SMALL = all_integrators<Dyn>::value;
@@ -461,12 +470,43 @@ template <typename T, typename Dyn> struct Stepper {
             for (int j = 0; j < NU; ++j) Du[i][j] = c * Kup[i][j];
         }
         Dyn::fjac(p, xs, u, k, Jx, Ju);
-        matmul<NX, NX, NX>(Jx, Dx, Kx);
-        matmul<NX, NX, NU>(Jx, Du, Ku);
+        if constexpr (second_order<Dyn>::value) {
+            // x = [q, q_dot], x_dot = [q_dot, a(q, q_dot, u)]: the top half of J_x is [0 I] and of J_u is 0, so
+            // the top rows of the products are rows of D (same values as multiplying through: 0 * d + 1 * d), and
+            // only the acceleration rows cost multiply-adds -- half of the chain rule's arithmetic
+            constexpr int NQ = NX / 2;
 #pragma unroll
-        for (int i = 0; i < NX; ++i)
+            for (int i = 0; i < NQ; ++i) {
 #pragma unroll
-            for (int j = 0; j < NU; ++j) Ku[i][j] += Ju[i][j];
+                for (int j = 0; j < NX; ++j) Kx[i][j] = Dx[NQ + i][j];
+#pragma unroll
+                for (int j = 0; j < NU; ++j) Ku[i][j] = Du[NQ + i][j];
+            }
+#pragma unroll
+            for (int i = NQ; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int s = 0; s < NX; ++s) acc += Jx[i][s] * Dx[s][j];
+                    Kx[i][j] = acc;
+                }
+#pragma unroll
+                for (int j = 0; j < NU; ++j) {
+                    T acc = T(0);
+#pragma unroll
+                    for (int s = 0; s < NX; ++s) acc += Jx[i][s] * Du[s][j];
+                    Ku[i][j] = acc + Ju[i][j];
+                }
+            }
+        } else {
+            matmul<NX, NX, NX>(Jx, Dx, Kx);
+            matmul<NX, NX, NU>(Jx, Du, Ku);
+#pragma unroll
+            for (int i = 0; i < NX; ++i)
+#pragma unroll
+                for (int j = 0; j < NU; ++j) Ku[i][j] += Ju[i][j];
+        }
     }
 
     // f, f_x, f_u of the discrete map at (x, u)

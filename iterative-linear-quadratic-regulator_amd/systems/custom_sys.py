@@ -148,6 +148,8 @@ def generate_dyn_bodies(f_cont, n_x, n_u):
     if len(out) != n_x:
         raise ValueError(f"_f_cont_fcn returned {len(out)} components, expected n_x = {n_x}")
     check_free(out, "_f_cont_fcn")
+    nq = n_x // 2
+    generate_dyn_bodies.second_order = n_x % 2 == 0 and all(sp.simplify(out[i] - xs[nq + i]) == 0 for i in range(nq))
     f_targets = [(f"xd[{i}]", e) for i, e in enumerate(out)]
     jac = list(f_targets)
     jac += [(f"Jx[{i}][{j}]", sp.diff(out[i], xs[j])) for i in range(n_x) for j in range(n_x)]
@@ -183,6 +185,7 @@ def render_plugin_source(f_cont, n_x, n_u, dtype, l_fcn=None, l_f_fcn=None):
         cost = ("        out = T(0);", "", "        out = T(0);", "")
     src = open(TEMPLATE).read()
     for key, val in (("@NX@", str(n_x)), ("@NU@", str(n_u)), ("@F_BODY@", f_body), ("@FJAC_BODY@", fjac_body),
+                     ("@SECOND_ORDER@", "true" if generate_dyn_bodies.second_order else "false"),
                      ("@CUSTOM_COST@", "true" if l_fcn is not None else "false"),
                      ("@L_BODY@", cost[0]), ("@L_DERIVS_BODY@", cost[1]), ("@LF_BODY@", cost[2]),
                      ("@LF_DERIVS_BODY@", cost[3]),
