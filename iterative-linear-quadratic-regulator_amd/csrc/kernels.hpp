@@ -780,16 +780,25 @@ __global__ void __launch_bounds__(256) select_kernel(KArgs<T> a) {
                 int acc = a.accepted[b];
                 const T c0 = a.cost[b];
                 if (!acc) {
-                    for (int ai = 0; ai < a.n_pass; ++ai) {
-                        const T c = a.costs[(size_t)ai * B + b];
-                        if (c <= c0) {  // NaN compares false, like the reference
-                            a.cur_slot[b] = (a.cur_slot[b] + 1 + ai) % a.n_slots;
-                            a.cost_prev[b] = c0;
-                            a.cost[b] = c;
-                            a.alpha_taken[b] = a.alphas[ai];
-                            acc = 1;
-                            break;
-                        }
+                    // all candidate costs are fetched before any is looked at: a first-match loop that loads as it
+                    // goes serialises up to n_pass memory round trips (measured: most of this kernel's 8 us)
+                    T cs[kMaxAlpha];
+#pragma unroll
+                    for (int ai = 0; ai < kMaxAlpha; ++ai) cs[ai] = ai < a.n_pass ? a.costs[(size_t)ai * B + b] : T(0);
+                    int first = -1;
+#pragma unroll
+                    for (int ai = kMaxAlpha - 1; ai >= 0; --ai)
+                        if (ai < a.n_pass && cs[ai] <= c0) first = ai;  // NaN compares false, like the reference
+                    if (first >= 0) {
+                        T c = cs[0], al = a.alphas[0];
+#pragma unroll
+                        for (int ai = 1; ai < kMaxAlpha; ++ai)
+                            if (ai == first) { c = cs[ai]; al = a.alphas[ai]; }
+                        a.cur_slot[b] = (a.cur_slot[b] + 1 + first) % a.n_slots;
+                        a.cost_prev[b] = c0;
+                        a.cost[b] = c;
+                        a.alpha_taken[b] = al;
+                        acc = 1;
                     }
                 }
                 if (a.last_pass) {
