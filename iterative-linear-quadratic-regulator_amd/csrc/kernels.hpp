@@ -97,7 +97,11 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     const int t = (int)(idx / B);
     const int b = (int)(idx % B);
     const bool inr = t <= a.N;                                  // a (b, t) point of the batch
-    const bool live = inr && traj_active(a.status[b]);
+    // status and slot are fetched together (the slot of a finished trajectory is simply not used): one memory
+    // round trip at the head of the wave instead of two dependent ones
+    const int st_raw = inr ? a.status[b] : 0;
+    const int slot_raw = inr ? a.cur_slot[b] : 0;
+    const bool live = inr && traj_active(st_raw);
     // the parameter block is read before the kernel's first store: hipcc then uses scalar loads (SGPRs); reads
     // that follow a store it cannot disambiguate become per-lane vector loads with their own vmcnt waits
     T p[PL::TOTAL];
@@ -111,7 +115,7 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     // slot 0 (16 MB at the c3 shape).  cur_slot[b] itself may only change once every block has read it, so that
     // is left to the kernel that always follows (the backward sweep, KArgs::reset_slots; SolverT::fix_slots for
     // any other order); the old slot keeps a valid copy until the next rollout overwrites it.
-    const int slot = live ? a.cur_slot[b] : 0;
+    const int slot = live ? slot_raw : 0;
     const bool move = live && slot != 0;
     const int tt = live ? t : 0;
     const int bb = live ? b : 0;
