@@ -654,12 +654,15 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     static_assert(PF >= 2, "ring too shallow to be worth it");
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int ai = blockIdx.y;
-    const bool live = b < a.B && traj_active(a.status[b < a.B ? b : 0]) && !a.accepted[b < a.B ? b : 0];
+    // status, accepted flag and slot in one memory round trip (bitwise &: no short-circuit between the loads)
+    const int bc = b < a.B ? b : 0;
+    const int st_raw = a.status[bc], acc_raw = a.accepted[bc], slot_raw = a.cur_slot[bc];
+    const bool live = (b < a.B) & traj_active(st_raw) & (acc_raw == 0);
     if (__ballot(live) == 0ull) return;
     const int bb = live ? b : 0;          // dead lanes shadow trajectory 0 and never store
     const size_t B = a.B;
     const int N = a.N;
-    const int slot = a.cur_slot[bb];
+    const int slot = slot_raw;            // (a dead lane's slot only selects which valid rows it reads and discards)
     const int cslot = (slot + 1 + ai) % a.n_slots;
     const T alpha = a.alphas[ai];
     // The parameter block is copied into registers once: the asm statements below carry "memory" clobbers
