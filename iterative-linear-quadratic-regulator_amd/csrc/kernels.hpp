@@ -79,6 +79,7 @@ struct ClockProbe {
 
 }  // namespace ilqr
 #include "backward_tile16.hpp"
+#include "backward_tile16m2.hpp"
 namespace ilqr {
 
 // ---------------------------------------------------------------------------
@@ -173,20 +174,21 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     T xn[NX], fx[NX][NX], fu[NX][NU];
     Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);  // integrator folded at compile time
     if constexpr (TILE16) {
-        // n_x = 4, n_u = 1: pack the 46 scalars into the 48-scalar tile of backward_tile16.hpp.  The 64
-        // tiles of a wave are contiguous in HBM (tile index = t*B + b = this lane's global index), but each
-        // lane holds ITS tile: a direct store would be 12 x 16-B pieces at a 192/384-B lane stride
-        // (measured 1.34x write amplification).  So the wave transposes through LDS in chunks and writes
-        // 16 B per lane to consecutive addresses.
-        static_assert(NX >= 2 && NX <= 4 && NU == 1, "tile packing is for n_x <= 4, n_u = 1");
+        // pack the expansion into the tile of backward_tile16.hpp (n_u = 1: 48 scalars) or backward_tile16m2.hpp
+        // (n_x = 4, n_u = 2: 64 scalars).  The 64 tiles of a wave are contiguous in HBM (tile index = t*B + b = this
+        // lane's global index), but each lane holds ITS tile: a direct store would be TV x 16-B pieces at a
+        // 192..512-B lane stride (measured 1.34x write amplification).  So the wave transposes through LDS in chunks
+        // and writes 16 B per lane to consecutive addresses.
+        static_assert((NX >= 2 && NX <= 4 && NU == 1) || (NX == 4 && NU == 2), "tile packing: n_x <= 4 with n_u = 1, or (4, 2)");
         using V4 = typename Vec4<T>::type;
+        constexpr int TV = NU == 1 ? 12 : 16;          // V4 per tile
         T gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
         Cost<T, Dyn>::grad(p, a.dt, x, u, gxn, gu1);
         Cost<T, Dyn>::hess(p, a.dt, x, u, lxxn, luxn, luu);
         // zero-pad to the 4 x 4 tile (a no-op for n_x = 4): padding states have no dynamics and no cost
         auto F = [&](int i, int j) -> T { return (i < NX && j < NX) ? fx[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
         auto L = [&](int i, int j) -> T { return (i < NX && j < NX) ? lxxn[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
-        V4 tile[12];
+        V4 tile[TV];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             tile[c].x = F((c + 0) & 3, c); tile[c].y = F((c + 1) & 3, c);
@@ -197,35 +199,49 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
             tile[4 + i].x = L(i, 0); tile[4 + i].y = L(i, 1);
             tile[4 + i].z = L(i, 2); tile[4 + i].w = L(i, 3);
         }
+        if constexpr (NU == 1) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int jj = j < NX ? j : 0;
-            tile[8 + j].x = j < NX ? fu[jj][0] : T(0);
-            tile[8 + j].y = j < NX ? gxn[jj] : T(0);
-            tile[8 + j].z = j < NX ? luxn[0][jj] : T(0);
-            tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
+            for (int j = 0; j < 4; ++j) {
+                const int jj = j < NX ? j : 0;
+                tile[8 + j].x = j < NX ? fu[jj][0] : T(0);
+                tile[8 + j].y = j < NX ? gxn[jj] : T(0);
+                tile[8 + j].z = j < NX ? luxn[0][jj] : T(0);
+                tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
+            }
+        } else {
+            // group j: f_u[j][0], f_u[j][1], l_x[j], l_ux[0][j] | l_ux[1][j], e0, e1, e2   (backward_tile16m2.hpp);
+            // the sweep's Q_uu is symmetric: the mean of l_uu[0][1] and l_uu[1][0] is stored
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tile[8 + 2 * j].x = fu[j][0]; tile[8 + 2 * j].y = fu[j][NU - 1];
+                tile[8 + 2 * j].z = gxn[j]; tile[8 + 2 * j].w = luxn[0][j];
+                tile[9 + 2 * j].x = luxn[NU - 1][j];
+                tile[9 + 2 * j].y = (j == 0) ? gu1[0] : ((j == 1) ? T(0.5) * (luu[0][NU - 1] + luu[NU - 1][0]) : T(0));
+                tile[9 + 2 * j].z = (j == 0) ? gu1[NU - 1] : ((j == 1) ? luu[NU - 1][NU - 1] : T(0));
+                tile[9 + 2 * j].w = (j == 0) ? luu[0][0] : T(0);
+            }
         }
         // two passes over groups of 32 whole tiles (so every pass writes one contiguous run of full cache lines).
         // One pass of 64 tiles in f32 needs 13 KB of LDS per wave and caps the kernel at 3 waves per SIMD; with
         // 6.6 KB it runs 4 (the VGPR limit) and hides more of its gather / store latency: 50 -> 46 us.
-        constexpr int PASSES = 2, TPP = 64 / PASSES, ROW = 13;   // 12 V4 per tile + 1 pad
+        constexpr int PASSES = 2, TPP = 64 / PASSES, ROW = TV + 1;   // TV V4 per tile + 1 pad
         __shared__ V4 xpose[TPP * ROW];
         const int lane = threadIdx.x;
         const unsigned long long okmask = __ballot(point);
-        V4* gout = reinterpret_cast<V4*>(a.lin) + (size_t)blockIdx.x * 64 * 12;   // first tile of this wave
+        V4* gout = reinterpret_cast<V4*>(a.lin) + (size_t)blockIdx.x * 64 * TV;   // first tile of this wave
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             if (ps) __syncthreads();
             if (lane / TPP == ps) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) xpose[(lane % TPP) * ROW + q] = tile[q];
+                for (int q = 0; q < TV; ++q) xpose[(lane % TPP) * ROW + q] = tile[q];
             }
             __syncthreads();
             // read back in 16-byte units, tile-major: one wave-instruction = 64 lanes x 16 B = 1 KiB of
             // consecutive addresses, whatever the scalar type (a 32-B f64 V4 split over two instructions
             // would leave every instruction writing half lines, which non-temporal stores punish)
             typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-            constexpr int UPT = 12 * (int)sizeof(T) / 4;           // 16-B units per tile: 12 / 24
+            constexpr int UPT = TV * (int)sizeof(T) / 4;           // 16-B units per tile: 12 / 24 (16 / 32)
             constexpr int UPV = (int)sizeof(T) / 4;                // units per V4: 1 / 2
             const u4* xs = reinterpret_cast<const u4*>(xpose);
             u4* gu = reinterpret_cast<u4*>(gout);

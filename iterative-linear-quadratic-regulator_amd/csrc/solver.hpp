@@ -92,7 +92,8 @@ template <typename T> struct Ops {
     int n_dev_params = 0;
     int n_sys_dev = 0;
     int lin_stride = 0;   // scalars per (b, t) in the expansion buffer
-    bool tile16 = false;  // expansion packed as 48-scalar tiles (n_x = 4, n_u = 1)
+    bool tile16 = false;  // expansion packed as tiles for the DPP sweeps (n_u = 1: 48 scalars, (4, 2): 64)
+    int tile_scalars = 0;
     bool lin_aos = false; // expansion stored as [N][B][E] records (n_x > 4, wave-cooperative kernels)
     bool canonical = false;  // linearize moves every current trajectory into slot 0 (then cur_slot is reset)
 };
@@ -138,16 +139,35 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
 template <typename T, typename Dyn> Ops<T> make_ops() {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     Ops<T> o;
-    constexpr bool TILE = (NU == 1 && NX >= 2 && NX <= 4);   // the DPP sweep; n_x < 4 rides the 4 x 4 tile zero-padded
+    constexpr bool TILE2 = (NX == 4 && NU == 2);              // backward_tile16m2.hpp
+    constexpr bool TILE = (NU == 1 && NX >= 2 && NX <= 4) || TILE2;   // the DPP sweeps; n_x < 4 rides the 4 x 4 tile zero-padded
+    constexpr int TSC = TILE2 ? kTile16M2 : kTile16;
     o.tile16 = TILE;
     o.canonical = true;
-    o.lin_stride = TILE ? kTile16 : (2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU);
+    o.lin_stride = TILE ? TSC : (2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU);
+    o.tile_scalars = TILE ? TSC : 0;
     set_integrator_ops<T, Dyn, TILE, 0>(o);
     set_integrator_ops<T, Dyn, TILE, 1>(o);
     set_integrator_ops<T, Dyn, TILE, 2>(o);
     set_integrator_ops<T, Dyn, TILE, 3>(o);
     set_integrator_ops<T, Dyn, TILE, 4>(o);
-    if constexpr (TILE) {
+    if constexpr (TILE2) {
+        o.backward = [](const KArgs<T>& a, hipStream_t s) {
+            // 16 trajectories per 256-thread workgroup, one workgroup per CU (see kTile16PinLds)
+            static const bool pinned = [] {
+                bool ok = hipFuncSetAttribute((const void*)backward_tile16m2_kernel<T, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kTile16PinLds) == hipSuccess;
+                ok = ok && hipFuncSetAttribute((const void*)backward_tile16m2_kernel<T, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, kTile16PinLds) == hipSuccess;
+                (void)hipGetLastError();
+                return ok && getenv("ILQR_BACKWARD_NO_PIN") == nullptr;
+            }();
+            const dim3 grid((a.B + 15) / 16), block(256);
+            const size_t lds = pinned ? kTile16PinLds : 0;
+            if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16m2_kernel<T, true>), grid, block, lds, s, a);
+            else ILQR_LAUNCH((backward_tile16m2_kernel<T, false>), grid, block, lds, s, a);
+        };
+    } else if constexpr (TILE) {
         // one wave = 4 trajectories x 16 lanes; 1024 single-wave workgroups at B = 4096 = one per SIMD
         o.backward = [](const KArgs<T>& a, hipStream_t s) {
             static const bool lds_ring = getenv("ILQR_BACKWARD_LDS_RING") != nullptr;  // A/B switch for profiling
@@ -420,6 +440,10 @@ template <typename T> class SolverT : public SolverBase {
             err = "no kernels compiled for this (system, n_x, n_u, dtype)";
             return ILQR_ERR_UNSUPPORTED;
         }
+        if (ops.tile_scalars == kTile16M2 && (size_t)N * B * kTile16M2 * sizeof(T) >= (1ull << 31)) {
+            err = "n_x = 4, n_u = 2: horizon * batch too large for the sweep's 32-bit tile offsets (< 2 GiB of tiles)";
+            return ILQR_ERR_UNSUPPORTED;
+        }
         ILQR_HIPCHK(hipSetDevice(c.device));
         if (c.stream) {
             stream = (hipStream_t)c.stream;
@@ -546,7 +570,10 @@ template <typename T> class SolverT : public SolverBase {
         }
         if (!ops.tile16) return down_tc(host, lin, E, N);
         const size_t n = (size_t)B * N * E;
-        hipLaunchKernelGGL(tile16_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, NX);
+        if (ops.tile_scalars == kTile16M2)
+            hipLaunchKernelGGL(tile16m2_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
+        else
+            hipLaunchKernelGGL(tile16_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, NX);
         ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
         return check_launch();
@@ -563,8 +590,11 @@ template <typename T> class SolverT : public SolverBase {
         }
         if (!ops.tile16) return up_tc(host, lin, E, N);
         ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
-        ILQR_HIPCHK(hipMemsetAsync(lin, 0, (size_t)N * B * kTile16 * sizeof(T), stream));
-        hipLaunchKernelGGL(tile16_scatter_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, NX);
+        ILQR_HIPCHK(hipMemsetAsync(lin, 0, (size_t)N * B * ops.tile_scalars * sizeof(T), stream));
+        if (ops.tile_scalars == kTile16M2)
+            hipLaunchKernelGGL(tile16m2_scatter_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
+        else
+            hipLaunchKernelGGL(tile16_scatter_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, NX);
         ILQR_HIPCHK(hipStreamSynchronize(stream));
         return check_launch();
     }

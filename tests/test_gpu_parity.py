@@ -455,14 +455,17 @@ def test_tensor_sweep_reproduces_the_system_sweep():
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_batch_members_do_not_see_each_other(dtype):
+@pytest.mark.parametrize("name", ["ua", "dp"])
+def test_batch_members_do_not_see_each_other(name, dtype):
     """A trajectory solved inside a ragged batch (dead lanes in the last wave, members that stop early and freeze while
     the others go on) ends bit-identical to the same trajectory solved alone: nothing a dead or finished lane does --
     dropped out-of-range stores, predicated stores, the slot moves of the linearisation -- leaks into its neighbours."""
     N, B = 41, 67
-    p = problems.ua_double_pendulum(N=N)
+    p = problems.ua_double_pendulum(N=N) if name == "ua" else problems.double_pendulum(N=N)
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], dtype)
     x0, U0 = problems.ua_batch(B, seed=3, restarts=True, N=N)
+    if name == "dp":
+        U0 = np.repeat(U0, 2, axis=1) * np.array([1.0, -0.5])[None, :, None]   # two controls
     x0 = x0 * np.linspace(0.0, 2.0, B)[:, None]
     s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=0.3, maxiter=12, verbose=False)
     X, U, cost = s.optimize_trajectory()
