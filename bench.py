@@ -251,6 +251,24 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
+        if world == 1 and not args.no_phase_timing:
+            # reported beside the throughput figure, outside every timed region above: the same batch
+            # solved to convergence with the reference's stopping rules (tol, maxiter 50, line-search failure)
+            hs = sysm.make_handle(horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=50,
+                                  device=local_rank, stream=stream)
+            hs.set_problem(x0, U0)
+            hs.solve()                       # warm-up (kernel paging, event creation)
+            hs.set_problem(x0, U0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            its, _ = hs.solve()
+            t_solve = time.perf_counter() - t0
+            stw = hs.get(_lib.STATUS) & 0xff
+            out["solve_to_convergence"] = {
+                "batch": B, "wall_ms": t_solve * 1e3, "iterations_mean": float(np.mean(its)), "iterations_max": int(np.max(its)),
+                "converged": int(np.sum(stw == _lib.TRAJ_CONVERGED)), "linesearch_failed": int(np.sum(stw == _lib.TRAJ_LINESEARCH_FAILED)),
+                "maxiter": int(np.sum(stw == _lib.TRAJ_MAXITER)), "tol": p["tol"]}
+            hs.close()
         print(json.dumps(out))
     if world > 1:
         dist.barrier(device_ids=[local_rank])
