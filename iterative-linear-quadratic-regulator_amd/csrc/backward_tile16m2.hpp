@@ -11,7 +11,8 @@
 //
 // Q_ux is computed twice, in column form (lane holds Q_ux[c][j]) for the gains and in row form (Q_ux[c][i]) for the
 // value update, the latter through V_xx's symmetry (see tile16_step_f32): no transposition through the LDS crossbar.
-// This first version leaves the instruction order and the tile loads to hipcc (one tile of lookahead).
+// The instruction order is left to hipcc; fp32 keeps a ring of 8 tiles in flight (asm loads, self-counted vmcnt),
+// fp64 leaves the loads to hipcc too (one tile of lookahead).
 #pragma once
 #include "backward_tile16.hpp"
 
@@ -38,6 +39,43 @@ ILQR_DEV void tile16m2_load(Tile16M2<T>& tl, __amdgpu_buffer_rsrc_t r, const Til
     BufLoad<4, T>::v4(r, o.gi, soff, tl.gi + 4);
     tl.lxx = BufLoad<0, T>::v1(r, o.vl, soff);
 }
+
+// ---- the tile ring (same technique and same rules as RawTile in backward_tile16.hpp: all loads of a slot in ONE asm
+// statement opening with s_nop 4, early-clobber outputs, waits counted by hand) -------------------------------------
+template <typename T> struct RawTileM2;
+template <> struct RawTileM2<float> {
+    static constexpr int NLOAD = 7;
+    f32x4n ski, skj, gj0, gj1;
+    typedef float f32x2n __attribute__((ext_vector_type(2)));
+    f32x2n gia, gib;   // f_u[i][0..1] ; l_ux[0..1][i]
+    float lxx;
+    ILQR_DEV void issue(const i32x4& srd, const TileOffsetsM2& o, int soff) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %7, %12, %13 offen\n\t"
+            "buffer_load_dwordx4 %1, %8, %12, %13 offen\n\t"
+            "buffer_load_dwordx4 %2, %9, %12, %13 offen\n\t"
+            "buffer_load_dwordx4 %3, %9, %12, %13 offen offset:16\n\t"
+            "buffer_load_dwordx2 %4, %10, %12, %13 offen\n\t"
+            "buffer_load_dwordx2 %5, %10, %12, %13 offen offset:12\n\t"
+            "buffer_load_dword %6, %11, %12, %13 offen"
+            : "=&v"(ski), "=&v"(skj), "=&v"(gj0), "=&v"(gj1), "=&v"(gia), "=&v"(gib), "=&v"(lxx)
+            : "v"(o.vi), "v"(o.vj), "v"(o.gj), "v"(o.gi), "v"(o.vl), "s"(srd), "s"(soff)
+            : "memory");
+    }
+    template <int N> ILQR_DEV void wait() {
+        asm volatile("s_waitcnt vmcnt(%7)"
+                     : "+v"(ski), "+v"(skj), "+v"(gj0), "+v"(gj1), "+v"(gia), "+v"(gib), "+v"(lxx) : "i"(N) : "memory");
+    }
+    ILQR_DEV void unpack(Tile16M2<float>& t) const {
+        t.ski[0] = ski.x; t.ski[1] = ski.y; t.ski[2] = ski.z; t.ski[3] = ski.w;
+        t.skj[0] = skj.x; t.skj[1] = skj.y; t.skj[2] = skj.z; t.skj[3] = skj.w;
+        t.gj[0] = gj0.x; t.gj[1] = gj0.y; t.gj[2] = gj0.z; t.gj[3] = gj0.w;
+        t.gj[4] = gj1.x; t.gj[5] = gj1.y; t.gj[6] = gj1.z; t.gj[7] = gj1.w;
+        t.gi[0] = gia.x; t.gi[1] = gia.y; t.gi[3] = gib.x; t.gi[4] = gib.y;
+        t.lxx = lxx;
+    }
+};
 
 // sum down the 4 rows of a column, result in every row
 template <typename T> ILQR_DEV T col_sum(T v) {
@@ -127,18 +165,62 @@ __global__ void __launch_bounds__(256) backward_tile16m2_kernel(KArgs<T> a) {
     const int rec_off = (int)((b * R + (i < 2 ? 4 * i + j : 8 + j)) * sizeof(T));
     const T m0 = T(j == 0), m1 = T(j == 1);
     bool all_pd = true;
-    Tile16M2<T> cur, nxt;
-    tile16m2_load(cur, rlin, off, uniform((N - 1) * tstride));
-    for (int t = N - 1; t >= 0; --t) {
-        const int tn = t > 0 ? t - 1 : 0;
-        tile16m2_load(nxt, rlin, off, uniform(tn * tstride));   // one tile of lookahead (independent of V)
+    auto do_step = [&](const Tile16M2<T>& c, int t) {
         T K0, K1, k0, k1;
         bool pd;
-        tile16m2_step<T, REG>(cur, m0, m1, a.mu, V, vx, K0, K1, k0, k1, pd);
+        tile16m2_step<T, REG>(c, m0, m1, a.mu, V, vx, K0, K1, k0, k1, pd);
         all_pd = all_pd && pd;
         const T out = (i == 0) ? K0 : ((i == 1) ? K1 : ((j == 0) ? k0 : k1));
         if (storer) buf_store1(rgain, rec_off, uniform(t * rstride), out);
-        cur = nxt;
+    };
+    if constexpr (sizeof(T) == 4) {
+        // fp32: D tiles per lane in flight, self-counted vmcnt (see backward_tile16_kernel); every step issues exactly
+        // NL loads and one store, so slot u has landed when at most (D-1)*(NL+1) younger operations are outstanding
+        constexpr int D = 8, NL = RawTileM2<T>::NLOAD;
+        static_assert((D - 1) * (NL + 1) <= 63, "vmcnt field");
+        int t = N - 1;
+        for (int r = N % D; r > 0; --r, --t) {   // remainder steps first, so that the ring runs whole passes only
+            Tile16M2<T> c;
+            tile16m2_load(c, rlin, off, uniform(t * tstride));
+            do_step(c, t);
+        }
+        if (t >= 0) {
+            const i32x4 srd = make_srd(a.lin, lin_bytes);
+            RawTileM2<T> ring[D];
+#pragma unroll
+            for (int u = 0; u < D; ++u) ring[u].issue(srd, off, uniform((t - u) * tstride));
+#pragma unroll
+            for (int u = 0; u < D; ++u) {   // first pass: the prologue's loads may be the only operations in flight
+                ring[u].template wait<(D - 1) * NL>();
+                Tile16M2<T> c;
+                ring[u].unpack(c);
+                do_step(c, t - u);
+                const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
+                ring[u].issue(srd, off, uniform(tn * tstride));
+            }
+            for (t -= D; t >= 0; t -= D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    ring[u].template wait<(D - 1) * (NL + 1)>();
+                    Tile16M2<T> c;
+                    ring[u].unpack(c);
+                    do_step(c, t - u);
+                    const int tn = (t - u - D) > 0 ? (t - u - D) : 0;   // clamped: branch-free refill, drained below
+                    ring[u].issue(srd, off, uniform(tn * tstride));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        // fp64: the loads are left to hipcc (one tile of lookahead)
+        Tile16M2<T> cur, nxt;
+        tile16m2_load(cur, rlin, off, uniform((N - 1) * tstride));
+        for (int t = N - 1; t >= 0; --t) {
+            const int tn = t > 0 ? t - 1 : 0;
+            tile16m2_load(nxt, rlin, off, uniform(tn * tstride));
+            do_step(cur, t);
+            cur = nxt;
+        }
     }
     if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
 }

@@ -15,7 +15,7 @@ usage: check_ring_kernels.py <hipcc stderr log>      (exit 1 and a list on viola
 import re
 import sys
 
-GUARDED = ("forward_ring_kernel", "backward_tile16_kernel")
+GUARDED = ("forward_ring_kernel", "backward_tile16_kernel", "backward_tile16m2_kernel")
 
 
 def parse(log_text):
