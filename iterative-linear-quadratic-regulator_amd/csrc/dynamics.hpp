@@ -82,8 +82,8 @@ template <> struct M<double> {
     static ILQR_DEV double sqrt(double x) { return ::sqrt(x); }
     static ILQR_DEV double abs(double x) { return fabs(x); }
     // same scheme as the float version: reduction by pi through the 1.5 * 2^52 rounding constant, near-minimax
-    // polynomials of degree 8 in r^2 on [-pi/2, pi/2] (Chebyshev-node fits computed with 40-digit arithmetic; error
-    // of the rounded polynomials 3.7e-17 / 1.6e-17), one sign for both values.  |error| <= ~1 ulp for |x| < 1e3.
+    // polynomials of degree 7 in r^2 on [-pi/2, pi/2] (Chebyshev-node fits computed with 40-digit arithmetic; error
+    // of the rounded polynomials 4.2e-17 / 1.4e-17), one sign for both values.  |error| <= ~1 ulp for |x| < 1e3.
     static ILQR_DEV void sincos(double x, double* sn, double* cs) {
         constexpr double kMagic = 6755399441055744.0;   // 1.5 * 2^52
         const double t = fma(x, 0x1.45f306dc9c883p-2, kMagic);
@@ -92,24 +92,22 @@ template <> struct M<double> {
         r = fma(-n, 0x1.1a62633145c07p-53, r);
         r = fma(-n, -0x1.f1976b7ed8fbcp-109, r);
         const double z = r * r;
-        double ps = -0x1.270e682f051a4p-57;
-        ps = fma(ps, z, 0x1.95050477e28a7p-49);
-        ps = fma(ps, z, -0x1.ae7ed8479c0cfp-41);
-        ps = fma(ps, z, 0x1.612460a028f3cp-33);
-        ps = fma(ps, z, -0x1.ae64567e422cdp-26);
-        ps = fma(ps, z, 0x1.71de3a556b61bp-19);
-        ps = fma(ps, z, -0x1.a01a01a01a009p-13);
-        ps = fma(ps, z, 0x1.1111111111111p-7);
+        double ps = 0x1.892efd890db97p-49;
+        ps = fma(ps, z, -0x1.ae4d771729416p-41);
+        ps = fma(ps, z, 0x1.6123f55a16315p-33);
+        ps = fma(ps, z, -0x1.ae64557c0cbf9p-26);
+        ps = fma(ps, z, 0x1.71de3a5419df5p-19);
+        ps = fma(ps, z, -0x1.a01a01a0184f4p-13);
+        ps = fma(ps, z, 0x1.1111111111104p-7);
         ps = fma(ps, z, -0x1.5555555555555p-3);
         const double s = fma(r * z, ps, r);
-        double pc = 0x1.d9462c98ff4d3p-62;
-        pc = fma(pc, z, -0x1.680acb0165568p-53);
-        pc = fma(pc, z, 0x1.ae7ef4057b587p-45);
-        pc = fma(pc, z, -0x1.93974a1b90fadp-37);
-        pc = fma(pc, z, 0x1.1eed8eff29abep-29);
-        pc = fma(pc, z, -0x1.27e4fb7789922p-22);
-        pc = fma(pc, z, 0x1.a01a01a01a014p-16);
-        pc = fma(pc, z, -0x1.6c16c16c16c17p-10);
+        double pc = -0x1.5e8cb6756109ep-53;
+        pc = fma(pc, z, 0x1.ae5759e5592bep-45);
+        pc = fma(pc, z, -0x1.9396f4137a4d0p-37);
+        pc = fma(pc, z, 0x1.1eed8e979ff66p-29);
+        pc = fma(pc, z, -0x1.27e4fb77023cap-22);
+        pc = fma(pc, z, 0x1.a01a01a019538p-16);
+        pc = fma(pc, z, -0x1.6c16c16c16c11p-10);
         pc = fma(pc, z, 0x1.5555555555555p-5);
         const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
         const int sign = __double2loint(t) << 31;       // parity of n
