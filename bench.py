@@ -114,6 +114,7 @@ def main():
                     help="f32 = the reference's own (JAX default) precision; f64 = the build's double mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true")
+    ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence extra (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,7 +252,7 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
-        if world == 1 and not args.no_phase_timing:
+        if world == 1 and not args.no_phase_timing and not args.no_solve_extra:
             # reported beside the throughput figure, outside every timed region above: the same batch
             # solved to convergence with the reference's stopping rules (tol, maxiter 50, line-search failure)
             hs = sysm.make_handle(horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=50,
