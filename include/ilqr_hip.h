@@ -226,6 +226,12 @@ int ilqr_eval_points(ilqr_handle h, int integrator, int npts, const void* x, con
 /* ---- MPC step (run_iLQR_MPC.py:116-143), device-resident ------------------- */
 /* plant state <- x0, warm start <- U_init, fresh solver state */
 int ilqr_mpc_reset(ilqr_handle h, const void* x0, const void* U_init);
+/* Restart of the controller on a solver that has already solved: plant state and x_0 <- x0, warm start <- U_init,
+ * while X, K, U_ff are KEPT.  This is the state run_iLQR_MPC.py enters its loop with: its "JIT warm-up" is one full
+ * optimize_trajectory() on the same solver object (run_iLQR_MPC.py:95), so step 0's alpha = 0 rollout runs through
+ * the warm-up's gains, u = U_init + K_warm (x - X_warm) (iLQR_class.py:257-259).  ilqr_mpc_reset is the cold start of
+ * run_iLQR_UA_MPC.py, whose warm-up calls the pure functions only (:114-124). */
+int ilqr_mpc_rearm(ilqr_handle h, const void* x0, const void* U_init);
 /* n_steps x { x_0 <- plant state; U <- warm start; solve; u0 = U[:,0]; plant step with
  * plant_integrator; warm start <- shift(U) repeating the last column }.
  * u_out [n_steps][B][n_u], x_out [n_steps][B][n_x] (state after each step), cost_out [n_steps][B]; may be NULL */

@@ -37,7 +37,7 @@ SYMBOLS = (
     "ilqr_create", "ilqr_create_custom", "ilqr_destroy", "ilqr_sync", "ilqr_set_problem", "ilqr_set", "ilqr_get",
     "ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_forward", "ilqr_select", "ilqr_iterate",
     "ilqr_solve", "ilqr_backward_pass", "ilqr_backward_tensors", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
-    "ilqr_mpc_run", "ilqr_status_reduce", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
+    "ilqr_mpc_rearm", "ilqr_mpc_run", "ilqr_status_reduce", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
 )
 
 
@@ -111,6 +111,7 @@ def load():
     lib.ilqr_forward_pass.argtypes = [vp, vp, cd, vp, vp, vp, vp, vp, vp, vp]
     lib.ilqr_eval_points.argtypes = [vp, ci, ci] + [vp] * 14
     lib.ilqr_mpc_reset.argtypes = [vp, vp, vp]
+    lib.ilqr_mpc_rearm.argtypes = [vp, vp, vp]
     lib.ilqr_mpc_run.argtypes = [vp, ci, vp, vp, vp]
     lib.ilqr_status_reduce.argtypes = [vp, vp]
     lib.ilqr_timing_enable.argtypes = [vp, ci]
@@ -312,6 +313,12 @@ class Handle:
         x0 = self._in(x0, (self.B, self.n_x))
         U_init = self._in(U_init, (self.B, self.n_u, self.N))
         self._chk(self.lib.ilqr_mpc_reset(self.h, _ptr(x0), _ptr(U_init)))
+
+    def mpc_rearm(self, x0, U_init):
+        """Restart the controller but keep X, K, U_ff of the previous solve (run_iLQR_MPC.py:95 warm-up carry)."""
+        x0 = self._in(x0, (self.B, self.n_x))
+        U_init = self._in(U_init, (self.B, self.n_u, self.N))
+        self._chk(self.lib.ilqr_mpc_rearm(self.h, _ptr(x0), _ptr(U_init)))
 
     def mpc_run(self, n_steps):
         u = np.empty((n_steps, self.B, self.n_u), dtype=self.np_dtype)

@@ -179,6 +179,15 @@ ILQR_DEV i32x4 make_srd(const void* base, unsigned bytes) {
 }
 
 template <typename T> struct RawTile;
+// A REFILL ties every destination to the slot's previous value ("+&v"): the statement then redefines the slot's own
+// registers, so whatever still needs the consumed tile must read it (or copy it) BEFORE the loads are issued.  With
+// plain outputs hipcc is free to sink the tail of the step below the issue; the old tile is then still live, the new
+// loads get a temporary register, and the temporary is copied into the slot's register later -- a copy of a register
+// whose load may not have landed (this produced wrong fp64 gains in round 1 and sat unnoticed in the mu > 0 fp32
+// sweep; csrc/verify_ring_isa.py now rejects any build that touches an in-flight destination).  The prologue's first
+// issue has nothing to tie to and uses early-clobber outputs.
+#define ILQR_OUT_FIRST(x) "=&v"(x)
+#define ILQR_OUT_REFILL(x) "+&v"(x)
 // All loads of a tile are ONE asm statement opening with s_nop 4: every SGPR operand (descriptor, soffset) is
 // then materialised before the statement, and a value hipcc produced with a VALU (v_readfirstlane, or a
 // v_readlane restoring a spilled SGPR) has its 5 wait states before a buffer instruction reads it -- hipcc
@@ -189,17 +198,20 @@ template <> struct RawTile<float> {
     static constexpr int NLOAD = 5;
     f32x4n ski, skj, vj, vi;   // vi = {f_u[i], l_x[i], l_ux[i], e_i}: the row-form twin of vj (f_u[i] and l_ux[i] used)
     float lxx;
-    ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "buffer_load_dwordx4 %0, %5, %8, %9 offen" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %1, %6, %8, %9 offen" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %2, %6, %8, %9 offen offset:128" ILQR_TILE_NT "\n\t"
-            "buffer_load_dword %3, %7, %8, %9 offen offset:64" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %4, %5, %8, %9 offen offset:128" ILQR_TILE_NT
-            : "=&v"(ski), "=&v"(skj), "=&v"(vj), "=&v"(lxx), "=&v"(vi)
-            : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)
-            : "memory");
+#define ILQR_RAWTILE_F32(OUT)                                                                \
+    asm volatile(                                                                            \
+        "s_nop 4\n\t"                                                                        \
+        "buffer_load_dwordx4 %0, %5, %8, %9 offen" ILQR_TILE_NT "\n\t"                       \
+        "buffer_load_dwordx4 %1, %6, %8, %9 offen" ILQR_TILE_NT "\n\t"                       \
+        "buffer_load_dwordx4 %2, %6, %8, %9 offen offset:128" ILQR_TILE_NT "\n\t"            \
+        "buffer_load_dword %3, %7, %8, %9 offen offset:64" ILQR_TILE_NT "\n\t"               \
+        "buffer_load_dwordx4 %4, %5, %8, %9 offen offset:128" ILQR_TILE_NT                   \
+        : OUT(ski), OUT(skj), OUT(vj), OUT(lxx), OUT(vi)                                     \
+        : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)                               \
+        : "memory")
+    template <bool FIRST> ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
+        if constexpr (FIRST) ILQR_RAWTILE_F32(ILQR_OUT_FIRST);
+        else ILQR_RAWTILE_F32(ILQR_OUT_REFILL);
     }
     template <int N> ILQR_DEV void wait() {
         asm volatile("s_waitcnt vmcnt(%5)" : "+v"(ski), "+v"(skj), "+v"(vj), "+v"(lxx), "+v"(vi) : "i"(N) : "memory");
@@ -215,20 +227,23 @@ template <> struct RawTile<double> {
     static constexpr int NLOAD = 8;
     f64x2n ski0, ski1, skj0, skj1, vj0, vj1;
     double lxx, bi;
-    ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "buffer_load_dwordx4 %0, %8, %11, %12 offen" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %1, %8, %11, %12 offen offset:16" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %2, %9, %11, %12 offen" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %3, %9, %11, %12 offen offset:16" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %4, %9, %11, %12 offen offset:256" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx4 %5, %9, %11, %12 offen offset:272" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx2 %6, %10, %11, %12 offen offset:128" ILQR_TILE_NT "\n\t"
-            "buffer_load_dwordx2 %7, %8, %11, %12 offen offset:256" ILQR_TILE_NT
-            : "=&v"(ski0), "=&v"(ski1), "=&v"(skj0), "=&v"(skj1), "=&v"(vj0), "=&v"(vj1), "=&v"(lxx), "=&v"(bi)
-            : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)
-            : "memory");
+#define ILQR_RAWTILE_F64(OUT)                                                                \
+    asm volatile(                                                                            \
+        "s_nop 4\n\t"                                                                        \
+        "buffer_load_dwordx4 %0, %8, %11, %12 offen" ILQR_TILE_NT "\n\t"                     \
+        "buffer_load_dwordx4 %1, %8, %11, %12 offen offset:16" ILQR_TILE_NT "\n\t"           \
+        "buffer_load_dwordx4 %2, %9, %11, %12 offen" ILQR_TILE_NT "\n\t"                     \
+        "buffer_load_dwordx4 %3, %9, %11, %12 offen offset:16" ILQR_TILE_NT "\n\t"           \
+        "buffer_load_dwordx4 %4, %9, %11, %12 offen offset:256" ILQR_TILE_NT "\n\t"          \
+        "buffer_load_dwordx4 %5, %9, %11, %12 offen offset:272" ILQR_TILE_NT "\n\t"          \
+        "buffer_load_dwordx2 %6, %10, %11, %12 offen offset:128" ILQR_TILE_NT "\n\t"         \
+        "buffer_load_dwordx2 %7, %8, %11, %12 offen offset:256" ILQR_TILE_NT                 \
+        : OUT(ski0), OUT(ski1), OUT(skj0), OUT(skj1), OUT(vj0), OUT(vj1), OUT(lxx), OUT(bi)  \
+        : "v"(o.vi), "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)                               \
+        : "memory")
+    template <bool FIRST> ILQR_DEV void issue(const i32x4& srd, const TileOffsets& o, int soff) {
+        if constexpr (FIRST) ILQR_RAWTILE_F64(ILQR_OUT_FIRST);
+        else ILQR_RAWTILE_F64(ILQR_OUT_REFILL);
     }
     template <int N> ILQR_DEV void wait() {
         asm volatile("s_waitcnt vmcnt(%8)"
@@ -495,7 +510,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     // lanes (0, j) store K[j], lane (1, 0) stores k.  fp32: every other lane's offset lies beyond the descriptor's
     // range, where the hardware drops the store -- no exec-mask juggling around the one counted store of a step.
     // (The same trick on the 64-bit store of the fp64 sweep produced wrong gains; it keeps the predicate.)
-    constexpr bool DROP = sizeof(T) == 4;
+    constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
     const bool storer = act && ((i == 0 && j < NXA) || l16 == 4);
     const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : NXA)) * sizeof(T)) : 0x7ffffff0;
     bool all_pd = true;
@@ -526,7 +541,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
         const i32x4 srd = make_srd(a.lin, lin_bytes);
         RawTile<T> ring[D];
 #pragma unroll
-        for (int u = 0; u < D; ++u) ring[u].issue(srd, off, uniform((t - u) * tstride));
+        for (int u = 0; u < D; ++u) ring[u].template issue<true>(srd, off, uniform((t - u) * tstride));
         // first ring pass: only the prologue's loads (plus this pass's own stores / refills) are in flight
 #pragma unroll
         for (int u = 0; u < D; ++u) {
@@ -535,7 +550,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
             ring[u].unpack(c);
             do_step(c, t - u);
             const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
-            ring[u].issue(srd, off, uniform(tn * tstride));
+            ring[u].template issue<false>(srd, off, uniform(tn * tstride));
         }
         for (t -= D; t >= 0; t -= D) {
 #pragma unroll
@@ -550,7 +565,7 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
                 // (Issuing the refill in the middle of the NEXT step instead, inside its latency-bound tail,
                 // was tried: 43.8 vs 40.6 us -- the extra asm statement splits hipcc's schedule of the tail.)
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
-                ring[u].issue(srd, off, uniform(tn * tstride));
+                ring[u].template issue<false>(srd, off, uniform(tn * tstride));
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

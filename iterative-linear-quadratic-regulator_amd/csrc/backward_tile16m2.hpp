@@ -49,19 +49,23 @@ template <> struct RawTileM2<float> {
     typedef float f32x2n __attribute__((ext_vector_type(2)));
     f32x2n gia, gib;   // f_u[i][0..1] ; l_ux[0..1][i]
     float lxx;
-    ILQR_DEV void issue(const i32x4& srd, const TileOffsetsM2& o, int soff) {
-        asm volatile(
-            "s_nop 4\n\t"
-            "buffer_load_dwordx4 %0, %7, %12, %13 offen\n\t"
-            "buffer_load_dwordx4 %1, %8, %12, %13 offen\n\t"
-            "buffer_load_dwordx4 %2, %9, %12, %13 offen\n\t"
-            "buffer_load_dwordx4 %3, %9, %12, %13 offen offset:16\n\t"
-            "buffer_load_dwordx2 %4, %10, %12, %13 offen\n\t"
-            "buffer_load_dwordx2 %5, %10, %12, %13 offen offset:12\n\t"
-            "buffer_load_dword %6, %11, %12, %13 offen"
-            : "=&v"(ski), "=&v"(skj), "=&v"(gj0), "=&v"(gj1), "=&v"(gia), "=&v"(gib), "=&v"(lxx)
-            : "v"(o.vi), "v"(o.vj), "v"(o.gj), "v"(o.gi), "v"(o.vl), "s"(srd), "s"(soff)
-            : "memory");
+#define ILQR_RAWTILE_M2(OUT)                                                                 \
+    asm volatile(                                                                            \
+        "s_nop 4\n\t"                                                                        \
+        "buffer_load_dwordx4 %0, %7, %12, %13 offen\n\t"                                     \
+        "buffer_load_dwordx4 %1, %8, %12, %13 offen\n\t"                                     \
+        "buffer_load_dwordx4 %2, %9, %12, %13 offen\n\t"                                     \
+        "buffer_load_dwordx4 %3, %9, %12, %13 offen offset:16\n\t"                           \
+        "buffer_load_dwordx2 %4, %10, %12, %13 offen\n\t"                                    \
+        "buffer_load_dwordx2 %5, %10, %12, %13 offen offset:12\n\t"                          \
+        "buffer_load_dword %6, %11, %12, %13 offen"                                          \
+        : OUT(ski), OUT(skj), OUT(gj0), OUT(gj1), OUT(gia), OUT(gib), OUT(lxx)               \
+        : "v"(o.vi), "v"(o.vj), "v"(o.gj), "v"(o.gi), "v"(o.vl), "s"(srd), "s"(soff)         \
+        : "memory")
+    // FIRST: prologue (early-clobber outputs); refills tie the destinations to the consumed tile (see RawTile)
+    template <bool FIRST> ILQR_DEV void issue(const i32x4& srd, const TileOffsetsM2& o, int soff) {
+        if constexpr (FIRST) ILQR_RAWTILE_M2(ILQR_OUT_FIRST);
+        else ILQR_RAWTILE_M2(ILQR_OUT_REFILL);
     }
     template <int N> ILQR_DEV void wait() {
         asm volatile("s_waitcnt vmcnt(%7)"
@@ -188,7 +192,7 @@ __global__ void __launch_bounds__(256) backward_tile16m2_kernel(KArgs<T> a) {
             const i32x4 srd = make_srd(a.lin, lin_bytes);
             RawTileM2<T> ring[D];
 #pragma unroll
-            for (int u = 0; u < D; ++u) ring[u].issue(srd, off, uniform((t - u) * tstride));
+            for (int u = 0; u < D; ++u) ring[u].template issue<true>(srd, off, uniform((t - u) * tstride));
 #pragma unroll
             for (int u = 0; u < D; ++u) {   // first pass: the prologue's loads may be the only operations in flight
                 ring[u].template wait<(D - 1) * NL>();
@@ -196,7 +200,7 @@ __global__ void __launch_bounds__(256) backward_tile16m2_kernel(KArgs<T> a) {
                 ring[u].unpack(c);
                 do_step(c, t - u);
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
-                ring[u].issue(srd, off, uniform(tn * tstride));
+                ring[u].template issue<false>(srd, off, uniform(tn * tstride));
             }
             for (t -= D; t >= 0; t -= D) {
 #pragma unroll
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(256) backward_tile16m2_kernel(KArgs<T> a) {
                     ring[u].unpack(c);
                     do_step(c, t - u);
                     const int tn = (t - u - D) > 0 ? (t - u - D) : 0;   // clamped: branch-free refill, drained below
-                    ring[u].issue(srd, off, uniform(tn * tstride));
+                    ring[u].template issue<false>(srd, off, uniform(tn * tstride));
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -10,7 +10,12 @@ only touches them to park VGPRs: there is no MFMA here) and report no VGPR spill
 lanes, or through them to scratch -- are harmless: they never move a ring register.  The library build fails on a violation; the plugin builder (systems/custom_sys.py) instead
 recompiles with the offending integrators routed to the compiler-scheduled forward_kernel.
 
-usage: check_ring_kernels.py <hipcc stderr log>      (exit 1 and a list on violation)
+A spill is only one way to touch an in-flight register; a plain register copy is another (it broke the fp64 sweep with
+dropped stores in round 1).  Given the compiler's assembly as a second argument, verify_ring_isa.py walks every path
+of the guarded kernels with the vmcnt queue simulated and rejects ANY access to the destination of an asm load that
+may still be in flight.
+
+usage: check_ring_kernels.py <hipcc stderr log> [<device .s>]      (exit 1 and a list on violation)
 """
 import re
 import sys
@@ -22,16 +27,16 @@ def parse(log_text):
     """-> list of dicts {name, vgprs, agprs, scratch, vspill} for every kernel in a resource-usage log."""
     out, cur = [], None
     for line in log_text.splitlines():
-        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        m = re.search(r"\bFunction Name: (\S+)", line)      # ("file:line:col: remark: ..." or "remark: file:line:col: ...")
         if m:
             cur = {"name": m.group(1), "vgprs": 0, "agprs": 0, "scratch": 0, "vspill": 0}
             out.append(cur)
             continue
         if cur is None:
             continue
-        for key, pat in (("vgprs", r"remark:\s+VGPRs: (\d+)"), ("agprs", r"remark:\s+AGPRs: (\d+)"),
-                         ("scratch", r"remark:\s+ScratchSize \[bytes/lane\]: (\d+)"),
-                         ("vspill", r"remark:\s+VGPRs Spill: (\d+)")):
+        for key, pat in (("vgprs", r"\s+VGPRs: (\d+)"), ("agprs", r"\s+AGPRs: (\d+)"),
+                         ("scratch", r"\s+ScratchSize \[bytes/lane\]: (\d+)"),
+                         ("vspill", r"\s+VGPRs Spill: (\d+)")):
             m = re.search(pat, line)
             if m:
                 cur[key] = int(m.group(1))
@@ -50,7 +55,21 @@ def forward_ring_integrator(name):
     return int(m.group(1)) if m else None
 
 
+def isa_violations(asm_path):
+    """Kernel names whose assembly touches the destination of an in-flight asm load (verify_ring_isa.py), plus the
+    full per-kernel result."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("ilqr_verify_ring_isa",
+                                                  os.path.join(os.path.dirname(os.path.abspath(__file__)), "verify_ring_isa.py"))
+    vri = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vri)
+    res = vri.verify_text(open(asm_path, errors="replace").read(), GUARDED)
+    return [k for k, r in res.items() if r["violations"]], res, vri
+
+
 if __name__ == "__main__":
+    # usage: check_ring_kernels.py <resource-usage log> [<device .s file>]
     ks = parse(open(sys.argv[1], errors="replace").read())
     guarded = [k for k in ks if any(g in k["name"] for g in GUARDED)]
     bad = violations(ks)
@@ -59,4 +78,14 @@ if __name__ == "__main__":
     if not guarded:
         sys.stderr.write("check_ring_kernels: no guarded kernel found in the log (was the remark flag passed?)\n")
         sys.exit(1)
-    sys.exit(1 if bad else 0)
+    n_isa = 0
+    if len(sys.argv) > 2:
+        bad_isa, res, vri = isa_violations(sys.argv[2])
+        n_isa = vri.report(res)
+        if len(res) != len(guarded):
+            sys.stderr.write(f"check_ring_kernels: {len(guarded)} guarded kernels in the log but {len(res)} in the assembly\n")
+            sys.exit(1)
+        print(f"ring kernels: {len(guarded)} guarded, {sum(r['asm_loads'] for r in res.values())} asm loads verified, "
+              f"{sum(len(r['assumptions']) for r in res.values())} store-skip branches assumed not taken, "
+              f"{len(bad)} spilling, {n_isa} in-flight register accesses")
+    sys.exit(1 if (bad or n_isa) else 0)

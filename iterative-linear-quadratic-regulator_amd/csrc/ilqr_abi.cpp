@@ -222,6 +222,7 @@ int ilqr_eval_points(ilqr_handle h, int integrator, int npts, const void* x, con
     return h->impl->eval_points(integrator, npts, x, u, outs);
 }
 int ilqr_mpc_reset(ilqr_handle h, const void* x0, const void* U_init) { ILQR_FWD(h, mpc_reset(x0, U_init)); }
+int ilqr_mpc_rearm(ilqr_handle h, const void* x0, const void* U_init) { ILQR_FWD(h, mpc_rearm(x0, U_init)); }
 int ilqr_mpc_run(ilqr_handle h, int n_steps, void* u_out, void* x_out, void* cost_out) {
     ILQR_FWD(h, mpc_run(n_steps, u_out, x_out, cost_out));
 }

@@ -31,6 +31,9 @@ namespace ilqr {
 #ifndef ILQR_NT_TILE_LOAD
 #define ILQR_NT_TILE_LOAD 0
 #endif
+#ifndef ILQR_DROP_ALL
+#define ILQR_DROP_ALL 0   // experiment switch: branch-free dropped stores in the fp64 kernels too
+#endif
 constexpr int kMaxAlpha = 16;
 constexpr int kCounterRing = 64;
 
@@ -38,7 +41,8 @@ template <typename T> struct KArgs {
     int B, N, n_slots, integ, maxiter, flags;
     int n_pass;      // alphas in this pass
     int last_pass;   // select: this is the last pass of the iteration
-    int init_mode;   // select: unconditional accept of candidate 0 (initial rollout)
+    int init_mode;   // head of a solve (iLQR_class.py:257-259): the rollout takes every trajectory whatever its previous status
+                     // and clears the active-count slot, select accepts candidate 0 unconditionally
     int counter_idx; // select: which ring counter receives the number of still-active trajectories
     T dt, tol, mu;
     T alphas[kMaxAlpha];
@@ -562,9 +566,12 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     constexpr int R = gain_record(NX, NU);
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int ai = blockIdx.y;
+    if (a.init_mode && blockIdx.x == 0 && ai == 0 && threadIdx.x == 0) a.counters[a.counter_idx] = 0;   // the select that follows counts into it
     if (b >= a.B) return;
-    if (!traj_active(a.status[b])) return;
-    if (a.accepted[b]) return;  // an earlier pass of this iteration already found its alpha
+    if (!a.init_mode) {
+        if (!traj_active(a.status[b])) return;
+        if (a.accepted[b]) return;  // an earlier pass of this iteration already found its alpha
+    }
     const size_t B = a.B;
     const int N = a.N;
     const int slot = a.cur_slot[b];
@@ -666,14 +673,17 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     // rollout arithmetic still fits the 256 without spilling (see csrc/check_ring_kernels.py)
     constexpr int SLOT_REGS = (NX + NU + R) * (int)sizeof(T) / 4;
     constexpr int PF_CNT = (63 / (NLD + NST)) + 1 > 6 ? 6 : (63 / (NLD + NST)) + 1;
-    constexpr int PF = PF_CNT * SLOT_REGS > 130 ? 130 / SLOT_REGS : PF_CNT;
+    // (the fp64 backward-Euler step -- Newton loop with an LU solve -- needs more registers of its own: one slot fewer)
+    constexpr int RING_CAP = (sizeof(T) == 8 && INTEG == ILQR_INT_BACKWARD_EULER) ? 104 : 130;
+    constexpr int PF = PF_CNT * SLOT_REGS > RING_CAP ? RING_CAP / SLOT_REGS : PF_CNT;
     static_assert(PF >= 2, "ring too shallow to be worth it");
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     const int ai = blockIdx.y;
     // status, accepted flag and slot in one memory round trip (bitwise &: no short-circuit between the loads)
     const int bc = b < a.B ? b : 0;
     const int st_raw = a.status[bc], acc_raw = a.accepted[bc], slot_raw = a.cur_slot[bc];
-    const bool live = (b < a.B) & traj_active(st_raw) & (acc_raw == 0);
+    const bool live = (b < a.B) & ((a.init_mode != 0) | (traj_active(st_raw) & (acc_raw == 0)));
+    if (a.init_mode && blockIdx.x == 0 && ai == 0 && threadIdx.x == 0) a.counters[a.counter_idx] = 0;   // the select that follows counts into it
     if (__ballot(live) == 0ull) return;
     const int bb = live ? b : 0;          // dead lanes shadow trajectory 0 and never store
     const size_t B = a.B;
@@ -705,7 +715,7 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     const __amdgpu_buffer_rsrc_t rXc = make_rsrc(a.X, bytesX), rUc = make_rsrc(a.U, bytesU);
     // (32-bit stores only: the same trick on the 64-bit stores of the fp64 kernels wrote wrong data in the sweep,
     // so fp64 keeps the exec-mask predicate)
-    constexpr bool DROP = sizeof(T) == 4;
+    constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
     const int kDropped = 0x7ffffff0;
     const int vXc = (live || !DROP) ? (int)(((size_t)cslot * (N + 1) * NX * B + bb) * sizeof(T)) : kDropped;
     const int vUc = (live || !DROP) ? (int)(((size_t)cslot * N * NU * B + bb) * sizeof(T)) : kDropped;
@@ -713,7 +723,12 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     const int vx = (int)(((size_t)slot * (N + 1) * NX * B + bb) * sizeof(T));
     const int vu = (int)(((size_t)slot * N * NU * B + bb) * sizeof(T));
     const int vg = (int)((size_t)bb * R * sizeof(T));
-    auto issue = [&](In& in, int t) { in.issue(rXc, rUc, srdG, vx, vu, vg, t * NX * rowB, t * NU * rowB, t * R * rowB, rowB); };
+    // first: the slot holds nothing yet (prologue); otherwise a refill, tied to the slot's consumed inputs
+    auto issue = [&](In& in, int t, auto first) {
+        in.template issue<decltype(first)::value>(rXc, rUc, srdG, vx, vu, vg, t * NX * rowB, t * NU * rowB, t * R * rowB, rowB);
+    };
+    constexpr std::true_type kFirst{};
+    constexpr std::false_type kRefill{};
     auto do_step = [&](const In& in, int t) {
         T dx[NX];
 #pragma unroll
@@ -742,26 +757,26 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     // leading remainder: one slot, fully waited (whole rings only in the pipelined loop)
     for (int r = N % PF; r > 0; --r, ++t) {
         In in;
-        issue(in, t);
+        issue(in, t, kFirst);
         in.template wait<0>();
         do_step(in, t);
     }
     if (t < N) {
         In ring[PF];
 #pragma unroll
-        for (int q = 0; q < PF; ++q) issue(ring[q], t + q);
+        for (int q = 0; q < PF; ++q) issue(ring[q], t + q, kFirst);
 #pragma unroll
         for (int q = 0; q < PF; ++q) {   // first pass: the prologue loads may be the only operations in flight
             ring[q].template wait<(PF - 1) * NLD>();
             do_step(ring[q], t + q);
-            issue(ring[q], (t + q + PF < N) ? t + q + PF : N - 1);
+            issue(ring[q], (t + q + PF < N) ? t + q + PF : N - 1, kRefill);
         }
         for (t += PF; t < N; t += PF) {
 #pragma unroll
             for (int q = 0; q < PF; ++q) {
                 ring[q].template wait<(PF - 1) * (NLD + NST)>();
                 do_step(ring[q], t + q);
-                issue(ring[q], (t + q + PF < N) ? t + q + PF : N - 1);   // clamped: branch-free refill
+                issue(ring[q], (t + q + PF < N) ? t + q + PF : N - 1, kRefill);   // clamped: branch-free refill
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -984,7 +999,7 @@ template <typename T> struct MpcArgs {
     T dt;
     const T* params;
     T* U; const int* cur_slot; T* x0; T* plant_x;
-    T* u_log; T* x_log; T* cost_log; const T* cost;  // logs: [n_steps][...][B] or NULL
+    T* u_log; T* x_log; T* cost_log; const T* cost;  // logs in the ABI layout [n_steps][B][...], or NULL
 };
 
 template <typename T, typename Dyn>
@@ -1004,11 +1019,11 @@ __global__ void __launch_bounds__(64) mpc_advance_kernel(MpcArgs<T> a) {
     for (int i = 0; i < NX; ++i) {
         a.plant_x[(size_t)i * B + b] = xn[i];
         a.x0[(size_t)i * B + b] = xn[i];
-        if (a.x_log) a.x_log[((size_t)a.step * NX + i) * B + b] = xn[i];
+        if (a.x_log) a.x_log[((size_t)a.step * B + b) * NX + i] = xn[i];
     }
 #pragma unroll
     for (int j = 0; j < NU; ++j)
-        if (a.u_log) a.u_log[((size_t)a.step * NU + j) * B + b] = u[j];
+        if (a.u_log) a.u_log[((size_t)a.step * B + b) * NU + j] = u[j];
     if (a.cost_log) a.cost_log[(size_t)a.step * B + b] = a.cost[b];
     for (int t = 0; t + 1 < a.N; ++t)
 #pragma unroll

@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(64) forward_wave_kernel(KArgs<T> a) {
     static_assert(64 % NX == 0 && 64 % NU == 0 && NX % PR == 0, "lane mapping needs NX, NU dividing 64");
     const int b = blockIdx.x, ai = blockIdx.y;
     const int lane = threadIdx.x;
-    if (!traj_active(a.status[b]) || a.accepted[b]) return;
+    if (a.init_mode && b == 0 && ai == 0 && lane == 0) a.counters[a.counter_idx] = 0;   // the select that follows counts into it
+    if (!a.init_mode && (!traj_active(a.status[b]) || a.accepted[b])) return;
     const size_t B = a.B;
     const int N = a.N;
     const int slot = a.cur_slot[b];

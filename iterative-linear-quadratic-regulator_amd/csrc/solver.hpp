@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdint>
@@ -43,6 +44,7 @@ struct SolverBase {
                              const void* K, void* Xn, void* Un, void* cost) = 0;
     virtual int eval_points(int integ, int npts, const void* x, const void* u, void** outs) = 0;
     virtual int mpc_reset(const void* x0, const void* U) = 0;
+    virtual int mpc_rearm(const void* x0, const void* U) = 0;
     virtual int mpc_run(int n_steps, void* u_out, void* x_out, void* cost_out) = 0;
     virtual int status_reduce(void* dev_out4) = 0;
     virtual int probe_dump(long long* dst, size_t n) = 0;
@@ -126,7 +128,10 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
         if constexpr (has_fwd_in<T, Dyn::NX, Dyn::NU>::value && ((ILQR_RING_INTEG_MASK >> I) & 1)) {
             // ring form: 32-bit buffer offsets into X (the largest tensor), and a switch for A/B runs
             static const bool plain = getenv("ILQR_FORWARD_PLAIN") != nullptr;
-            const bool fits = (size_t)a.n_slots * (a.N + 1) * Dyn::NX * a.B * sizeof(T) < (1ull << 31);
+            // (X is the largest state tensor, U <= X; the gain tensor can be larger than X when n_alpha is small)
+            const size_t bytes_x = (size_t)a.n_slots * (a.N + 1) * Dyn::NX * a.B * sizeof(T);
+            const size_t bytes_g = (size_t)a.N * a.B * gain_record(Dyn::NX, Dyn::NU) * sizeof(T);
+            const bool fits = std::max(bytes_x, bytes_g) < (1ull << 31);
             if (fits && !plain) {
                 ILQR_LAUNCH((forward_ring_kernel<T, Dyn, I>), grid, block, 0, s, a);
                 return;
@@ -172,7 +177,9 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
         o.backward = [](const KArgs<T>& a, hipStream_t s) {
             static const bool lds_ring = getenv("ILQR_BACKWARD_LDS_RING") != nullptr;  // A/B switch for profiling
             // the register-ring kernel addresses both tensors through 32-bit buffer offsets
-            const bool fits = (size_t)a.N * a.B * kTile16 * sizeof(T) < (1ull << 31);
+            // (the gain tensor, gain_record(NX, 1) <= 8 scalars per (t, b), is always the smaller of the two)
+            const bool fits = (size_t)a.N * a.B * kTile16 * sizeof(T) < (1ull << 31) &&
+                              (size_t)a.N * a.B * gain_record(NX, 1) * sizeof(T) < (1ull << 31);
             if (lds_ring || !fits) {
                 const dim3 grid((a.B + 3) / 4), block(64);
                 if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16_lds_kernel<T, true, NX>), grid, block, 0, s, a);
@@ -366,6 +373,8 @@ template <typename T> class SolverT : public SolverBase {
     T* staging = nullptr;   // dense staging for layout conversion
     size_t staging_elems = 0;
     T* plant_x = nullptr;
+    T* eval_buf = nullptr;      // scratch of eval_points, grown on demand (the host-loop MPC calls f_fcn once per step)
+    size_t eval_cap = 0;
     T *mpc_u_log = nullptr, *mpc_x_log = nullptr, *mpc_cost_log = nullptr;
     int mpc_log_steps = 0;
     long long* probe = nullptr;  // device, 8 x int64 (see ClockProbe)
@@ -384,6 +393,7 @@ template <typename T> class SolverT : public SolverBase {
         hipFree(params);
         hipFree(staging);
         hipFree(plant_x);
+        hipFree(eval_buf);
         hipFree(probe);
         hipFree(mpc_u_log);
         hipFree(mpc_x_log);
@@ -465,7 +475,10 @@ template <typename T> class SolverT : public SolverBase {
         ILQR_HIPCHK(hipMemcpy(params, dpt.data(), dpt.size() * sizeof(T), hipMemcpyHostToDevice));
         int rc = alloc_state(st, A + 1);
         if (rc) return rc;
-        staging_elems = (size_t)B * std::max((size_t)(N + 1) * NX, std::max((size_t)N * NU * NX, (size_t)N * E));
+        // every layout conversion goes through `staging`: trajectories, gains, the expansion, and the small per-trajectory
+        // blocks (padded terminal expansion of the tile sweeps: 20; trial costs: up to kMaxAlpha)
+        staging_elems = (size_t)B * std::max({(size_t)(N + 1) * NX, (size_t)N * NU * NX, (size_t)N * E, (size_t)20,
+                                              (size_t)kMaxAlpha, (size_t)(NX + NX * NX)});
         ILQR_HIPCHK(hipMalloc((void**)&staging, staging_elems * sizeof(T)));
         ILQR_HIPCHK(hipMalloc((void**)&plant_x, (size_t)NX * B * sizeof(T)));
         ILQR_HIPCHK(hipMemsetAsync(plant_x, 0, (size_t)NX * B * sizeof(T), stream));
@@ -502,9 +515,15 @@ template <typename T> class SolverT : public SolverBase {
 
     // ---- layout conversion helpers (dense host layout <-> device) ------------------
     unsigned grid_for(size_t n) const { return (unsigned)((n + 255) / 256); }
+    int staging_check(size_t n) {
+        if (n <= staging_elems) return ILQR_OK;
+        err = "internal: layout-conversion staging buffer too small for this call";
+        return ILQR_ERR_INVALID_ARG;
+    }
 
     int up_ct(const void* host, T* slots, const int* cur_slot, int C, int Tn) {
         const size_t n = (size_t)B * C * Tn;
+        if (int rs_ = staging_check(n)) return rs_;
         ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(scatter_ct_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, slots, cur_slot, B, C, Tn);
         ILQR_HIPCHK(hipStreamSynchronize(stream));  // the caller's host buffer may be released after return
@@ -512,6 +531,7 @@ template <typename T> class SolverT : public SolverBase {
     }
     int down_ct(void* host, const T* slots, const int* cur_slot, int C, int Tn) {
         const size_t n = (size_t)B * C * Tn;
+        if (int rs_ = staging_check(n)) return rs_;
         hipLaunchKernelGGL(gather_ct_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, slots, cur_slot, B, C, Tn);
         ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -519,6 +539,7 @@ template <typename T> class SolverT : public SolverBase {
     }
     int up_tc(const void* host, T* dev, int C, int Tn) {
         const size_t n = (size_t)B * C * Tn;
+        if (int rs_ = staging_check(n)) return rs_;
         ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(scatter_tc_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, dev, B, C, Tn);
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -526,6 +547,7 @@ template <typename T> class SolverT : public SolverBase {
     }
     int down_tc(void* host, const T* dev, int C, int Tn) {
         const size_t n = (size_t)B * C * Tn;
+        if (int rs_ = staging_check(n)) return rs_;
         hipLaunchKernelGGL(gather_tc_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, dev, B, C, Tn);
         ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -534,6 +556,7 @@ template <typename T> class SolverT : public SolverBase {
 
     int up_gain_K(const void* host, T* gains) {
         const size_t n = (size_t)B * N * NU * NX;
+        if (int rs_ = staging_check(n)) return rs_;
         ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(gains_scatter_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU * NX, R);
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -541,6 +564,7 @@ template <typename T> class SolverT : public SolverBase {
     }
     int down_gain_K(void* host, const T* gains) {
         const size_t n = (size_t)B * N * NU * NX;
+        if (int rs_ = staging_check(n)) return rs_;
         hipLaunchKernelGGL(gains_gather_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU * NX, R);
         ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -548,6 +572,7 @@ template <typename T> class SolverT : public SolverBase {
     }
     int up_gain_k(const void* host, T* gains) {
         const size_t n = (size_t)B * N * NU;
+        if (int rs_ = staging_check(n)) return rs_;
         ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(gains_scatter_k_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU, NU * NX, R);
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -555,6 +580,7 @@ template <typename T> class SolverT : public SolverBase {
     }
     int down_gain_k(void* host, const T* gains) {
         const size_t n = (size_t)B * N * NU;
+        if (int rs_ = staging_check(n)) return rs_;
         hipLaunchKernelGGL(gains_gather_k_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, gains, B, N, NU, NU * NX, R);
         ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
         ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -563,6 +589,7 @@ template <typename T> class SolverT : public SolverBase {
     int down_lin(void* host, const T* lin) {
         if (ops.lin_aos) {
             const size_t n = (size_t)B * N * E;
+            if (int rs_ = staging_check(n)) return rs_;
             hipLaunchKernelGGL(gains_gather_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, E, E);
             ILQR_HIPCHK(hipMemcpyAsync(host, staging, n * sizeof(T), hipMemcpyDeviceToHost, stream));
             ILQR_HIPCHK(hipStreamSynchronize(stream));
@@ -570,6 +597,7 @@ template <typename T> class SolverT : public SolverBase {
         }
         if (!ops.tile16) return down_tc(host, lin, E, N);
         const size_t n = (size_t)B * N * E;
+        if (int rs_ = staging_check(n)) return rs_;
         if (ops.tile_scalars == kTile16M2)
             hipLaunchKernelGGL(tile16m2_gather_dense_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N);
         else
@@ -582,6 +610,7 @@ template <typename T> class SolverT : public SolverBase {
     // dense [B][N][E] expansion records -> the layout the backward kernel of this (n_x, n_u) reads
     int up_lin(const void* host, T* lin) {
         const size_t n = (size_t)B * N * E;
+        if (int rs_ = staging_check(n)) return rs_;
         if (ops.lin_aos) {
             ILQR_HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(T), hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(gains_scatter_K_kernel<T>, dim3(grid_for(n)), dim3(256), 0, stream, staging, lin, B, N, E, E);
@@ -707,12 +736,14 @@ template <typename T> class SolverT : public SolverBase {
         s.slots_stale = false;
         return check_launch();
     }
-    int do_forward(DeviceState<T>& s, const double* alphas, int n) {
+    int do_forward(DeviceState<T>& s, const double* alphas, int n, bool init = false) {
         if (n < 1 || n > s.n_slots - 1 || n > kMaxAlpha) { err = "forward: alpha count out of range"; return ILQR_ERR_INVALID_ARG; }
         int rcf = fix_slots(s);
         if (rcf) return rcf;
         KArgs<T> a = kargs(s);
         a.n_pass = n;
+        a.init_mode = init;     // head of a solve: every trajectory rolls out, counter slot 0 is cleared
+        a.counter_idx = 0;
         for (int i = 0; i < n; ++i) a.alphas[i] = (T)alphas[i];
         timer.begin(ILQR_PHASE_FORWARD, stream);
         ops.forward[cfg.integrator](a, stream);
@@ -736,12 +767,11 @@ template <typename T> class SolverT : public SolverBase {
     int initial_rollout() override {
         if (!have_problem) { err = "initial_rollout before set_problem"; return ILQR_ERR_STATE; }
         int rc;
-        // all trajectories take part in the head of a solve, whatever their previous status
-        ILQR_HIPCHK(hipMemsetAsync(st.status, 0, (size_t)B * sizeof(int), stream));
-        ILQR_HIPCHK(hipMemsetAsync(st.accepted, 0, (size_t)B * sizeof(int), stream));
-        ILQR_HIPCHK(hipMemsetAsync(st.counters, 0, kCounterRing * sizeof(int), stream));
+        // All trajectories take part in the head of a solve, whatever their previous status: the rollout's init mode
+        // ignores status / accepted and clears counter slot 0, the select's init mode rewrites status, iteration count
+        // and accepted flag of every trajectory -- two launches, no memsets (an MPC step used to pay three).
         const double zero = 0.0;
-        if ((rc = do_forward(st, &zero, 1))) return rc;
+        if ((rc = do_forward(st, &zero, 1, true))) return rc;
         if ((rc = do_select(st, &zero, 1, false, true, 0))) return rc;
         have_rollout = true;
         iter_seq = 0;
@@ -853,6 +883,15 @@ template <typename T> class SolverT : public SolverBase {
         // ones is to stop launching once nobody is left.  The host reads it ONE ITERATION LATE: iteration i + 1 is
         // already queued when it waits for the count of iteration i, so the stream never drains for the read-back
         // (the price is one surplus iteration of early-exiting kernels at the end of a solve).
+        // Short loops (the pendulum MPC of run_iLQR_MPC.py runs maxiter = 10) are simply enqueued whole: a finished
+        // trajectory is skipped inside every kernel, so surplus iterations cost a few microseconds of early-exiting
+        // launches each, less than one host round trip.
+        static const int enqueue_all = getenv("ILQR_SOLVE_ENQUEUE_ALL") ? atoi(getenv("ILQR_SOLVE_ENQUEUE_ALL")) : 12;
+        if (cfg.maxiter <= enqueue_all) {
+            for (int i = 0; i < cfg.maxiter; ++i)
+                if ((rc = one_iteration(nullptr))) return rc;
+            return ILQR_OK;
+        }
         int prev = -1;
         for (int i = 0; i < cfg.maxiter; ++i) {
             int cidx;
@@ -961,8 +1000,15 @@ template <typename T> class SolverT : public SolverBase {
                                   (size_t)NX * NX, (size_t)NU * NX, (size_t)NU * NU, 1, (size_t)NX, (size_t)NX * NX};
         size_t total = (size_t)NX + NU;
         for (int i = 0; i < 12; ++i) total += sizes[i];
-        T* buf = nullptr;
-        ILQR_HIPCHK(hipMalloc((void**)&buf, total * npts * sizeof(T)));
+        if (total * npts > eval_cap) {     // grown on demand, kept: no hipMalloc / hipFree per call
+            ILQR_HIPCHK(hipStreamSynchronize(stream));
+            hipFree(eval_buf);
+            eval_buf = nullptr;
+            eval_cap = 0;
+            ILQR_HIPCHK(hipMalloc((void**)&eval_buf, total * npts * sizeof(T)));
+            eval_cap = total * npts;
+        }
+        T* buf = eval_buf;
         T* dx = buf;
         T* du = dx + (size_t)npts * NX;
         T* cur = du + (size_t)npts * NU;
@@ -986,7 +1032,6 @@ template <typename T> class SolverT : public SolverBase {
         for (int i = 0; i < 12 && e == hipSuccess; ++i)
             if (outs[i]) e = hipMemcpyAsync(outs[i], dout[i], sizes[i] * npts * sizeof(T), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        hipFree(buf);
         if (e != hipSuccess) { err = std::string("eval_points: ") + hipGetErrorString(e); return ILQR_ERR_HIP; }
         return ILQR_OK;
     }
@@ -996,6 +1041,22 @@ template <typename T> class SolverT : public SolverBase {
         int rc = set_problem(x0, U);
         if (rc) return rc;
         if ((rc = up_tc(x0, plant_x, NX, 1))) return rc;
+        mpc_ready = true;
+        return ILQR_OK;
+    }
+
+    // Controller restart that KEEPS the solver state: x_0 and plant state <- x0, warm start <- U, while X, K, U_ff stay
+    // what the previous solve left.  run_iLQR_MPC.py warms up with one full optimize_trajectory() (:95) and then enters
+    // its loop on the same solver object, so step 0's alpha = 0 rollout is u = U_guess + K_warm (x - X_warm)
+    // (SURVEY Q1 / Q2); mpc_reset() is the cold start of run_iLQR_UA_MPC.py, whose warm-up is side-effect free.
+    int mpc_rearm(const void* x0, const void* U) override {
+        if (!x0 || !U) { err = "mpc_rearm: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        if (!have_problem) { err = "mpc_rearm before set_problem / mpc_reset"; return ILQR_ERR_STATE; }
+        int rc;
+        if ((rc = fix_slots(st))) return rc;
+        if ((rc = up_tc(x0, st.x0, NX, 1))) return rc;
+        if ((rc = up_tc(x0, plant_x, NX, 1))) return rc;
+        if ((rc = up_ct(U, st.U, st.cur_slot, NU, N))) return rc;
         mpc_ready = true;
         return ILQR_OK;
     }
@@ -1024,17 +1085,10 @@ template <typename T> class SolverT : public SolverBase {
             timer.end(stream);
             if ((rc = check_launch())) return rc;
         }
-        // logs are [step][c][B] on the device; the ABI promises [step][B][c]
-        std::vector<T> tmp;
+        // the kernel writes the logs in the ABI's own layout [step][B][c]: one plain copy each
         auto fetch = [&](void* host, const T* dev, int C) -> int {
             if (!host) return ILQR_OK;
-            tmp.resize((size_t)n_steps * C * B);
-            ILQR_HIPCHK(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
-            ILQR_HIPCHK(hipStreamSynchronize(stream));
-            T* out = (T*)host;
-            for (int s = 0; s < n_steps; ++s)
-                for (int c = 0; c < C; ++c)
-                    for (int b = 0; b < B; ++b) out[((size_t)s * B + b) * C + c] = tmp[((size_t)s * C + c) * B + b];
+            ILQR_HIPCHK(hipMemcpyAsync(host, dev, (size_t)n_steps * C * B * sizeof(T), hipMemcpyDeviceToHost, stream));
             return ILQR_OK;
         };
         int rc;

@@ -204,8 +204,12 @@ class iLQR:
             print(f"Warning: Reached max iterations ({self.maxiter}) without converging.")
 
     # ---- MPC (run_iLQR_MPC.py:116-143), device-resident ---------------------------------------------
-    def mpc_reset(self, x_0, U_init):
-        self._h.mpc_reset(self._in(x_0, (self.n_x,)), self._in(U_init, (self.n_u, self.N)))
+    def mpc_reset(self, x_0, U_init, keep_state=False):
+        """Start the device-resident controller at plant state x_0 with warm start U_init.  keep_state=True keeps
+        X, K, U_ff of the solve that ran before (the reference's run_iLQR_MPC.py enters its loop after a full warm-up
+        optimize_trajectory(), :95); the default is a fresh solver (run_iLQR_UA_MPC.py:114-124)."""
+        fn = self._h.mpc_rearm if keep_state else self._h.mpc_reset
+        fn(self._in(x_0, (self.n_x,)), self._in(U_init, (self.n_u, self.N)))
 
     def mpc_run(self, n_steps):
         """n_steps receding-horizon steps on the device.  Returns (U_sim, X_sim, cost) with shapes

@@ -32,7 +32,7 @@ from .system_base import System
 PLUGIN_ROOT = os.path.join(_lib.HERE, "_plugins")
 TEMPLATE = os.path.join(_lib.CSRC, "plugin_template.hip.in")
 _KERNEL_HEADERS = ("dynamics.hpp", "kernels.hpp", "backward_tile16.hpp", "backward_tile16m2.hpp", "kernels_wave.hpp", "fwd_in_gen.inc",
-                   "solver.hpp", "plugin_template.hip.in")
+                   "solver.hpp", "plugin_template.hip.in", "check_ring_kernels.py", "verify_ring_isa.py")
 
 
 def _ring_check():
@@ -213,32 +213,44 @@ def build_plugin(source, verbose=False):
     hip = os.path.join(d, "plugin.hip")
     with open(hip, "w") as fh:
         fh.write(source)
-    tmp = so + f".tmp{os.getpid()}"
+    # every build works in a directory of its own (threads or ranks building the same system at the same time share
+    # `d`, and the compiler's kept temporaries have fixed names); the finished library is moved into place atomically
+    import tempfile
+    work = tempfile.mkdtemp(prefix="build.", dir=d)
+    tmp = os.path.join(work, "ilqr_system_plugin.so")
     crk = _ring_check()
     base = [hipcc, "-shared", "-fPIC", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fvisibility=hidden",
-            "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage", "-I", _lib.CSRC,
+            "-ffp-contract=on", "-Rpass-analysis=kernel-resource-usage", "-save-temps=obj", "-I", _lib.CSRC,
             "-I", os.path.join(_lib.HERE, "..", "include"), "-o", tmp, hip]
+    asm = os.path.join(work, "plugin-hip-amdgcn-amd-amdhsa-gfx950.s")
+
     mask = 0x1F
     for attempt in range(2):
         r = subprocess.run(base + [f"-DILQR_RING_INTEG_MASK={mask}"], capture_output=True, text=True)
         if r.returncode != 0:
             print(r.stderr[-8000:])
+            shutil.rmtree(work, ignore_errors=True)
             raise RuntimeError(f"compiling the system plugin failed ({hip})")
-        # the ring kernels count their own memory operations and must not spill (check_ring_kernels.py): route
-        # the integrators whose rollout does to the compiler-scheduled kernel and compile once more
-        bad = crk.violations(crk.parse(r.stderr))
+        # The ring kernels count their own memory operations: they must not spill (check_ring_kernels.py) and nothing
+        # may touch a register whose asm load can still be in flight (verify_ring_isa.py, on the compiler's assembly).
+        # Integrators whose rollout violates either are routed to the compiler-scheduled kernel; compile once more.
+        bad = [k["name"] for k in crk.violations(crk.parse(r.stderr))]
+        bad += [k for k in crk.isa_violations(asm)[0] if k not in bad]
         if verbose:
-            print(f"plugin {tag}: ring mask {mask:#x}, spilling ring kernels: {[k['name'] for k in bad]}")
+            print(f"plugin {tag}: ring mask {mask:#x}, rejected ring kernels: {bad}")
         if not bad:
             break
-        integ = [crk.forward_ring_integrator(k["name"]) for k in bad]
+        integ = [crk.forward_ring_integrator(k) for k in bad]
         if attempt == 1 or any(i is None for i in integ):
-            raise RuntimeError("a self-counted ring kernel spills in this plugin build: " + ", ".join(k["name"] for k in bad))
+            shutil.rmtree(work, ignore_errors=True)
+            raise RuntimeError("a self-counted ring kernel spills or touches an in-flight register in this plugin build: "
+                               + ", ".join(bad))
         for i in integ:
             mask &= ~(1 << i)
     with open(os.path.join(d, "ring_mask.txt"), "w") as fh:
         fh.write(f"{mask:#x}\n")
     os.replace(tmp, so)  # atomic: concurrent ranks building the same system never load a partial file
+    shutil.rmtree(work, ignore_errors=True)
     return so
 
 

@@ -419,10 +419,11 @@ REAL FN(oracle_forward)(const void* Mv, int N, const REAL* x0, REAL alpha, const
  * optimize_trajectory (iLQR_class.py:250-313).  State X, U, Uff, K is carried in and out (quirk Q1).
  * fixed_iters > 0: throughput mode -- run exactly that many iterations, never break (bench.py cpu_baseline).
  * Returns the number of backward passes executed; *status: 1 converged, 2 line-search failed, 3 maxiter.
+ * alpha_hist / cost_hist (may be NULL): [maxiter] accepted alpha (0 = none) and cost after each iteration executed.
  */
-int FN(oracle_solve)(const void* Mv, int N, const REAL* x0, REAL* X, REAL* U, REAL* Uff, REAL* K, double tol,
-                     int maxiter, double alpha_factor, double min_alpha, int n_trials, int fixed_iters,
-                     REAL* cost_out, int* status) {
+int FN(oracle_solve_hist)(const void* Mv, int N, const REAL* x0, REAL* X, REAL* U, REAL* Uff, REAL* K, double tol,
+                          int maxiter, double alpha_factor, double min_alpha, int n_trials, int fixed_iters,
+                          REAL* cost_out, int* status, double* alpha_hist, REAL* cost_hist) {
     const model_t* M = (const model_t*)Mv;
     const int n = M->n, m = M->m;
     REAL* Xn = (REAL*)malloc(sizeof(REAL) * n * (N + 1));
@@ -452,6 +453,9 @@ int FN(oracle_solve)(const void* Mv, int N, const REAL* x0, REAL* X, REAL* U, RE
             alpha *= alpha_factor;
             if (alpha < min_alpha) break;
         }
+        /* per-iteration trace for the parity tests: accepted alpha (0 = none) and the cost after the iteration */
+        if (alpha_hist) alpha_hist[i] = accepted ? alpha : 0.0;
+        if (cost_hist) cost_hist[i] = cost;
         if (!accepted && fixed_iters <= 0) { st = 2; break; }
     }
     free(Xn);
@@ -459,6 +463,13 @@ int FN(oracle_solve)(const void* Mv, int N, const REAL* x0, REAL* X, REAL* U, RE
     *cost_out = cost;
     *status = st;
     return iters;
+}
+
+int FN(oracle_solve)(const void* Mv, int N, const REAL* x0, REAL* X, REAL* U, REAL* Uff, REAL* K, double tol,
+                     int maxiter, double alpha_factor, double min_alpha, int n_trials, int fixed_iters,
+                     REAL* cost_out, int* status) {
+    return FN(oracle_solve_hist)(Mv, N, x0, X, U, Uff, K, tol, maxiter, alpha_factor, min_alpha, n_trials, fixed_iters,
+                                 cost_out, status, 0, 0);
 }
 
 /* single point: f, f_x, f_u (tests) */

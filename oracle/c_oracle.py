@@ -65,7 +65,7 @@ class COracle:
         g = lambda name: getattr(lib, name + sfx)
         self._create, self._destroy = g("oracle_model_create"), g("oracle_model_destroy")
         self._backward, self._forward, self._solve, self._step = g("oracle_backward"), g("oracle_forward"), \
-            g("oracle_solve"), g("oracle_step")
+            g("oracle_solve_hist"), g("oracle_step")
         self._create.restype = C.c_void_p
         self._create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_int]
         self._destroy.argtypes = [C.c_void_p]
@@ -74,7 +74,8 @@ class COracle:
         self._forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, self.real] + [C.c_void_p] * 6
         self._solve.restype = C.c_int
         self._solve.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_double, C.c_int, C.c_double, C.c_double,
-                                                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                                                                          C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                                          C.c_void_p, C.c_void_p]
         self._step.argtypes = [C.c_void_p] * 6
         self.M = self._create(_SYS[dynamics["kind"]], _INT[integ], n, m, float(dynamics["dt"]),
                               p.ctypes.data_as(C.c_void_p), nsys)
@@ -122,10 +123,16 @@ class COracle:
             X, Uff, K = (self._a(s).copy() for s in state)
         cost = self.real(0)
         st = C.c_int(0)
+        n_hist = max(int(fixed_iters), int(maxiter), 1)
+        alpha_hist = np.zeros(n_hist, np.float64)
+        cost_hist = np.zeros(n_hist, self.dtype)
         it = self._solve(self.M, N, self._p(x0), self._p(X), self._p(U), self._p(Uff), self._p(K), tol, maxiter,
-                         alpha_factor, min_alpha, n_trials, fixed_iters, C.byref(cost), C.byref(st))
+                         alpha_factor, min_alpha, n_trials, fixed_iters, C.byref(cost), C.byref(st),
+                         self._p(alpha_hist), self._p(cost_hist))
         status = {1: "converged", 2: "linesearch_failed", 3: "maxiter"}[st.value]
-        return dict(X=X, U=U, U_ff=Uff, K=K, cost=self.dtype.type(cost.value), iterations=it, status=status)
+        # alphas / costs: accepted alpha (0 = none) and cost after each backward pass executed (iLQR_class.py:279-302)
+        return dict(X=X, U=U, U_ff=Uff, K=K, cost=self.dtype.type(cost.value), iterations=it, status=status,
+                    alphas=alpha_hist[:it].copy(), costs=cost_hist[:it].copy())
 
     def step(self, x, u, jac=True):
         x, u = self._a(x), self._a(u)

@@ -185,9 +185,16 @@ class iLQROracle:
         return self.X, self.U, cost
 
 
-def mpc_closed_loop(solver, plant, x_0, U_init, n_sim):
+def mpc_closed_loop(solver, plant, x_0, U_init, n_sim, warmup=False):
     """Receding-horizon loop of run_iLQR_MPC.py:116-143: set x_0 and U, solve,
-    apply the first control to the plant, shift the warm start (repeat last)."""
+    apply the first control to the plant, shift the warm start (repeat last).
+
+    warmup=True reproduces run_iLQR_MPC.py:95: ONE full optimize_trajectory() on the same solver object before
+    the loop ("JIT warm-up").  It leaves X, K, U_ff behind, and the loop's first solve starts from them (its alpha = 0
+    rollout is u = U_init + K_warm (x - X_warm), iLQR_class.py:257-259).  run_iLQR_UA_MPC.py warms
+    up through the pure backward_pass / forward_pass instead (:114-124) and starts cold: warmup=False."""
+    if warmup:
+        solver.optimize_trajectory()
     dt = solver.system.dtype
     X_sim = np.zeros((solver.n_x, n_sim + 1), dtype=dt)
     U_sim = np.zeros((solver.n_u, n_sim), dtype=dt)

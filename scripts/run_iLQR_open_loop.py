@@ -14,6 +14,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ilqr_amd.iLQR_class import iLQR                                  # noqa: E402
 from ilqr_amd.systems.pendulum_sys import MyPendulum                   # noqa: E402
 from ilqr_amd.systems.UA_double_pendulum_sys import MyUADoublePendulum  # noqa: E402
@@ -37,14 +38,15 @@ def build(kind, dtype):
     return system, T, N, x_0, np.zeros((system.n_u, N)), tol, maxiter
 
 
-def main():
+def main(argv=None):
+    """Runs the driver; returns what it computed (the tests call this and compare with the oracle)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--system", default="pendulum", choices=["pendulum", "ua"])
     ap.add_argument("--batch", type=int, default=0, help="0 = the reference's single trajectory; B>0 = B perturbed starts")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--plot", default=None)
+    ap.add_argument("--plot", default=None, help="write the reference's figure (run_iLQR_open_loop.py:115-145) to this file")
     ap.add_argument("--quiet", action="store_true")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
     dtype = np.float64 if a.dtype == "f64" else np.float32
     print("Setting up parameters...")
     system, T, N, x_0, U_init, tol, maxiter = build(a.system, dtype)
@@ -54,7 +56,7 @@ def main():
         U_init = np.zeros((a.batch,) + U_init.shape)
     solver = iLQR(system=system, T=T, x_0=x_0, U_init=U_init, tol=tol, maxiter=maxiter, verbose=not a.quiet)
 
-    print("Warming up ...")   # the reference warms up the JIT; here it pages in the kernels
+    print("Warming up ...")   # the reference warms up the JIT (:78-93); here it pages in the kernels
     Xw, Uw = np.zeros_like(solver.X), np.zeros_like(solver.U)
     solver.backward_pass(Xw, Uw)[0].block_until_ready()
     solver.forward_pass(solver.x_0, 0.0, Xw, Uw, np.zeros_like(solver.U_ff), np.zeros_like(solver.K))[0].block_until_ready()
@@ -70,23 +72,16 @@ def main():
         print(f"final cost {cost:.6f}  status {solver.status}  iterations {solver.iterations}")
         print(f"final state {np.asarray(X_bar)[:, -1]}")
     if a.plot:
-        import matplotlib
-        matplotlib.use("Agg")
-        import matplotlib.pyplot as plt
+        print("Plotting results...")
+        from _plots import open_loop_figure
         Xp = np.asarray(X_bar if not a.batch else X_bar[0])
         Up = np.asarray(U_bar if not a.batch else U_bar[0])
-        t = np.arange(N + 1) * system.dt
-        fig, ax = plt.subplots(system.n_x + 1, 1, figsize=(9, 2.2 * (system.n_x + 1)), sharex=True)
-        for i in range(system.n_x):
-            ax[i].plot(t, Xp[i], "b-")
-            ax[i].axhline(system.x_target[i], color="r", ls="--")
-            ax[i].set_ylabel(f"x[{i}]")
-        ax[-1].plot(t[:-1], Up[0], "k-")
-        ax[-1].set_ylabel("u")
-        ax[-1].set_xlabel("Time (s)")
-        fig.tight_layout()
-        fig.savefig(a.plot)
+        open_loop_figure(a.plot, solver.tspan, Xp, Up)
         print("wrote", a.plot)
+    print("\n--- Summary ---")
+    print(f"iLQR solver time:      {dt_solve:.4f} seconds")
+    return dict(X=np.asarray(X_bar), U=np.asarray(U_bar), cost=cost, status=solver.status, iterations=solver.iterations,
+                K=np.asarray(solver.K), U_ff=np.asarray(solver.U_ff), N=N, seconds=dt_solve)
 
 
 if __name__ == "__main__":

@@ -48,6 +48,30 @@ def case(name, p, N, B, maxiter, seed, restarts=True, integrator=None):
     print(name, "cost", np.array(cs), "iters", its, sts)
 
 
+def mpc_warm_case():
+    """run_iLQR_MPC.py as written: one full warm-up solve on the solver object (:95), then the loop (:116-143)."""
+    p = problems.pendulum_mpc(N=40)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    plant = oracle_from_spec(p["dynamics"], p["cost"], integrator=p["plant_integrator"])
+    o = iLQROracle(orc, N=40, x_0=p["x0"], U_init=p["U_init"], tol=p["tol"], maxiter=p["maxiter"])
+    X, U, c = mpc_closed_loop(o, plant, p["x0"], p["U_init"], 8, warmup=True)
+    np.savez_compressed(os.path.join(HERE, "mpc_pendulum_warm.npz"), X_sim=X, U_sim=U, cost=c, N=40, n_sim=8)
+    print("mpc_pendulum_warm", c)
+
+
+def open_loop_script_case():
+    """c1 exactly as run_iLQR_open_loop.py runs it (:16-69): T = 4 s -> N = 400, backward_euler, one trajectory,
+    x0 = [1, 0], U_init = 0, tol 1e-5, maxiter 100."""
+    p = problems.pendulum_open_loop(integrator="backward_euler", N=400)
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    o = iLQROracle(orc, N=400, x_0=p["x0"], U_init=p["U_init"], tol=p["tol"], maxiter=p["maxiter"])
+    X, U, c = o.optimize_trajectory()
+    np.savez_compressed(os.path.join(HERE, "c1_pendulum_be_n400.npz"), X=X, U=U, cost=c, K=o.K, U_ff=o.U_ff,
+                        iterations=o.iterations, status=o.status, initial_cost=o.initial_cost,
+                        alphas=np.array([h[1] for h in o.history]), costs=np.array([h[2] for h in o.history]))
+    print("c1_pendulum_be_n400 cost", c, o.status, o.iterations)
+
+
 def mpc_case():
     p = problems.pendulum_mpc(N=40)
     orc = oracle_from_spec(p["dynamics"], p["cost"])
@@ -65,3 +89,5 @@ if __name__ == "__main__":
     case("c2_ua_be", problems.ua_double_pendulum(integrator="backward_euler"), N=40, B=2, maxiter=6, seed=4)
     case("dp_rk4", problems.double_pendulum(), N=40, B=2, maxiter=6, seed=5)
     mpc_case()
+    mpc_warm_case()
+    open_loop_script_case()
