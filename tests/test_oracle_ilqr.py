@@ -85,7 +85,8 @@ def test_c_oracle_full_solve_agrees():
         np.testing.assert_allclose(r["K"], o.K, rtol=1e-6, atol=1e-9)
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "c*_*.npz")) + glob.glob(os.path.join(GOLD, "dp_*.npz"))))
+@pytest.mark.parametrize("path", [os.path.join(GOLD, f + ".npz") for f in
+                                  ("c1_pendulum_be", "c1_pendulum_rk4", "c2_ua_be", "c2_ua_rk4", "dp_rk4")])
 def test_golden_fixtures_reproduce(path):
     g = np.load(path)
     name = os.path.basename(path)
@@ -155,3 +156,49 @@ def test_fp32_switch_stays_fp32():
     o = iLQROracle(orc, N=20, x_0=x0[0], U_init=U0[0], maxiter=2)
     X, U, c = o.optimize_trajectory()
     assert X.dtype == np.float32 and o.K.dtype == np.float32 and np.asarray(c).dtype == np.float32
+
+
+def test_golden_open_loop_driver_case_reproduces():
+    """c1 as run_iLQR_open_loop.py runs it (N = 400, backward_euler, batch 1): NumPy oracle == golden == C oracle."""
+    g = np.load(os.path.join(GOLD, "c1_pendulum_be_n400.npz"))
+    p = problems.pendulum_open_loop(integrator="backward_euler", N=400)
+    o = iLQROracle(oracle_from_spec(p["dynamics"], p["cost"]), N=400, x_0=p["x0"], U_init=p["U_init"], tol=p["tol"],
+                   maxiter=p["maxiter"])
+    X, U, c = o.optimize_trajectory()
+    np.testing.assert_allclose(c, g["cost"], rtol=1e-10)
+    np.testing.assert_allclose(U, g["U"], rtol=1e-9, atol=1e-12)
+    assert o.status == str(g["status"]) and o.iterations == int(g["iterations"])
+    np.testing.assert_allclose([h[1] for h in o.history], g["alphas"])
+    r = COracle(p["dynamics"], p["cost"]).solve(p["x0"], p["U_init"], tol=p["tol"], maxiter=p["maxiter"])
+    assert (r["status"], r["iterations"]) == (o.status, o.iterations)
+    np.testing.assert_allclose(r["cost"], c, rtol=1e-9)
+    np.testing.assert_allclose(r["alphas"], g["alphas"])
+    np.testing.assert_allclose(r["costs"], g["costs"], rtol=1e-9)
+
+
+def test_mpc_warm_up_solve_is_part_of_the_closed_loop():
+    """run_iLQR_MPC.py:95: the driver's warm-up is one full solve on the solver object; its X, K, U_ff enter
+    step 0 of the loop.  Golden vector of the warm loop; warm != cold; the C oracle's `state` carry gives the same."""
+    g = np.load(os.path.join(GOLD, "mpc_pendulum_warm.npz"))
+    p = problems.pendulum_mpc(N=int(g["N"]))
+    orc = oracle_from_spec(p["dynamics"], p["cost"])
+    plant = oracle_from_spec(p["dynamics"], p["cost"], integrator=p["plant_integrator"])
+    mk = lambda: iLQROracle(orc, N=p["N"], x_0=p["x0"], U_init=p["U_init"], tol=p["tol"], maxiter=p["maxiter"])
+    Xw, Uw, cw = mpc_closed_loop(mk(), plant, p["x0"], p["U_init"], int(g["n_sim"]), warmup=True)
+    np.testing.assert_allclose(cw, g["cost"], rtol=1e-10)
+    np.testing.assert_allclose(Uw, g["U_sim"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(Xw, g["X_sim"], rtol=1e-9, atol=1e-12)
+    Xc, Uc, cc = mpc_closed_loop(mk(), plant, p["x0"], p["U_init"], int(g["n_sim"]), warmup=False)
+    assert np.abs(Uw - Uc).max() > 1e-8
+    # C oracle: warm-up solve, then the loop with the state carried in
+    co = COracle(p["dynamics"], p["cost"])
+    cp = COracle(p["dynamics"], p["cost"], integrator=p["plant_integrator"])
+    r = co.solve(p["x0"], p["U_init"], tol=p["tol"], maxiter=p["maxiter"])
+    state, x, U_guess = (r["X"], r["U_ff"], r["K"]), np.asarray(p["x0"], float), np.asarray(p["U_init"], float)
+    for k in range(int(g["n_sim"])):
+        r = co.solve(x, U_guess, tol=p["tol"], maxiter=p["maxiter"], state=state)
+        x = cp.step(x, r["U"][:, 0], jac=False)[0]
+        np.testing.assert_allclose(r["U"][:, 0], g["U_sim"][:, k], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(x, g["X_sim"][:, k + 1], rtol=1e-8, atol=1e-11)
+        U_guess = np.concatenate([r["U"][:, 1:], r["U"][:, -1:]], axis=1)
+        state = (r["X"], r["U_ff"], r["K"])
