@@ -36,32 +36,52 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
+PHASE_KERNEL = {"linearize": "linearize_kernel", "backward": "backward_tile16_kernel", "forward": "forward_ring_kernel"}
+
+
 def pmc_traffic(dtype, batch, horizon):
-    """HBM bytes per backward launch from the committed rocprofv3 PMC passes (profiles/rNN/pmc_traffic_*.json;
-    FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).  Counters cannot be read from inside this
-    process, so the figure is the profiled one for the same (dtype, batch, horizon), else None."""
+    """HBM bytes per launch of the three hot kernels from the committed rocprofv3 PMC passes (newest
+    profiles/rNN/pmc_traffic_*.json for the same dtype, batch, horizon; FETCH_SIZE doubled per the gfx950 correction,
+    + WRITE_SIZE).  Counters cannot be read from inside this process, so the figure is the profiled one, else None."""
     import glob
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_traffic_{dtype}.json"))):
         try:
             d = json.load(open(path))
             if d.get("batch") == batch and d.get("horizon") == horizon:
-                best = (float(d["kernels"]["backward_tile16_kernel"]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT))
+                best = ({ph: float(d["kernels"][k]["hbm_bytes_per_launch"]) for ph, k in PHASE_KERNEL.items()
+                         if k in d["kernels"]}, os.path.relpath(path, ROOT))
         except Exception:
             pass
     return best
 
 
 def host_cores():
-    """Cores this process may actually use (the GPU box gives a 1-GPU job a share of the host)."""
+    """(share, all): the cores of a 1-GPU job's share of the host (the pool gives one GPU 16 of them:
+    ILQR_BENCH_CORES), and every core this process may be scheduled on (its affinity mask)."""
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(n, os.cpu_count() or n, int(os.environ.get("ILQR_BENCH_CORES", "16"))))
+    n = max(1, min(n, os.cpu_count() or n))
+    return max(1, min(n, int(os.environ.get("ILQR_BENCH_CORES", "16")))), n
 
 
-def cpu_baseline(p, dtype, budget_s=10.0):
+def numpy_restatement_rate(p, dtype):
+    """The NumPy restatement (oracle/ilqr.py: explicit per-timestep loops, the form SURVEY 8d names) on ONE core:
+    one trajectory, two iterations of the same problem -- it is ~two orders slower than the C port."""
+    from oracle import iLQROracle
+    from oracle.build import oracle_from_spec
+    from ilqr_amd import problems
+    np_dt = np.float64 if dtype == "f64" else np.float32
+    x0, U0 = problems.ua_batch(1, seed=0, restarts=False, N=p["N"])
+    o = iLQROracle(oracle_from_spec(p["dynamics"], p["cost"], dtype=np_dt), N=p["N"], x_0=x0[0], U_init=U0[0], tol=0.0, maxiter=2)
+    t0 = time.perf_counter()
+    o.optimize_trajectory()
+    return o.iterations / (time.perf_counter() - t0)
+
+
+def cpu_baseline(p, dtype, cores, budget_s=10.0):
     """The oracle's C restatement of the reference loop (oracle/c/ilqr_oracle.c: per-timestep backward
     and forward passes, SEQUENTIAL backtracking that stops at the first accepted alpha, one trajectory
     per call) on the host cores: a bounded sample of the same workload, one forked worker per core."""
@@ -69,7 +89,6 @@ def cpu_baseline(p, dtype, budget_s=10.0):
     from oracle.c_oracle import COracle, build
     from ilqr_amd import problems
     build()
-    cores = host_cores()
     iters = 10
     np_dt = np.float64 if dtype == "f64" else np.float32
     x0, U0 = problems.ua_batch(256, seed=0, restarts=False, N=p["N"])
@@ -98,9 +117,30 @@ def cpu_baseline(p, dtype, budget_s=10.0):
         pr.join()
     wall = time.perf_counter() - t0
     return {"value": n_traj * iters / wall, "unit": "iLQR iterations/sec", "cores": cores, "kind": "port",
-            "single_core_value": iters / t1, "host_cpu_count": os.cpu_count(),
+            "single_core_value": iters / t1, "host_cpu_count": os.cpu_count(), "affinity_cores": host_cores()[1],
             "sample": f"{n_traj} trajectories x {iters} iterations of the same c3 problem ({dtype}); C restatement of the "
                       f"reference loop with its sequential backtracking; {cores} worker processes, {wall:.1f} s"}
+
+
+def mpc_c4_extra(ilqr_amd, _lib, problems, np_dt, device, stream, B=1024, n_sim=10):
+    """BASELINE config c4 at one GPU's shard, reported beside the headline (outside every timed region above): 1024
+    warm-started MPC instances of the under-actuated double pendulum, N = 200, rk4 optimiser, backward_euler plant,
+    tol 1e-5, maxiter 50 (run_iLQR_UA_MPC.py:17-174), `n_sim` receding-horizon steps device-resident (ilqr_mpc_run)."""
+    p = problems.ua_double_pendulum(N=200)
+    x0, U0 = problems.ua_batch(B, seed=2, restarts=False, N=200)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
+    h = sysm.make_handle(horizon=200, batch=B, n_alpha=10, n_trials=10, tol=p["tol"], maxiter=p["maxiter"],
+                         plant_integrator="backward_euler", device=device, stream=stream)
+    h.mpc_reset(x0, U0)
+    h.mpc_run(2)                       # cold start: the first solves run to maxiter; not part of the steady figure
+    t0 = time.perf_counter()
+    u, x, c = h.mpc_run(n_sim)         # returns after the logs have been copied back (synchronous)
+    wall = time.perf_counter() - t0
+    its = h.get(_lib.ITERS)
+    h.close()
+    return {"instances": B, "horizon": 200, "maxiter": p["maxiter"], "steps": n_sim, "ms_per_mpc_step": 1e3 * wall / n_sim,
+            "instance_steps_per_sec": B * n_sim / wall, "iterations_last_step_mean": float(np.mean(its)),
+            "iterations_last_step_max": int(np.max(its)), "all_finite": bool(np.isfinite(c).all())}
 
 
 def main():
@@ -114,7 +154,9 @@ def main():
                     help="f32 = the reference's own (JAX default) precision; f64 = the build's double mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true")
-    ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence extra (profiling runs)")
+    ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence / MPC extras (profiling runs)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="N = 1 only: run the per-step inter-GPU status exchange anyway, over a ONE-rank RCCL group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,9 +167,13 @@ def main():
     from ilqr_amd import _lib, problems
     p = problems.ua_double_pendulum(integrator="rk4", N=200)
     # CPU baseline first: its worker processes are forked before this process touches the GPU
-    cpu = None
+    cpu = cpu_all = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(p, args.dtype)
+        share, every = host_cores()
+        cpu = cpu_baseline(p, args.dtype, share)
+        cpu["numpy_restatement_single_core_value"] = numpy_restatement_rate(p, args.dtype)
+        if every > share:      # P = every core the job may run on; the pool may still throttle it to its share
+            cpu_all = cpu_baseline(p, args.dtype, every, budget_s=6.0)
 
     import torch
     import torch.distributed as dist
@@ -141,6 +187,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")  # RCCL
+    elif args.exchange:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    exchange = world > 1 or args.exchange
 
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     B, N = args.batch, p["N"]
@@ -157,17 +210,17 @@ def main():
                          device=local_rank, flags=_lib.FLAG_KEEP_ITERATING, stream=stream)
     h.set_problem(x0, U0)       # uploads: inputs are HBM-resident from here on
     h.initial_rollout()
-    xchg = StatusExchange(device=f"cuda:{local_rank}") if world > 1 else None
+    xchg = StatusExchange(device=f"cuda:{local_rank}") if exchange else None
 
     def step():
         h.iterate(1)
-        if world > 1:
+        if exchange:
             # the path's only inter-GPU exchange: best cost / convergence, as one 32-B all-gather
             # over RCCL on a side stream, so the compute stream never waits for it
             xchg.launch(lambda t: h.status_reduce(t.data_ptr()))
 
     def fence():
-        if world > 1:
+        if exchange:
             xchg.result()            # the last exchange has landed on every rank
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
@@ -239,12 +292,22 @@ def main():
             tr = pmc_traffic(args.dtype, B, N)
             out["roofline"] = {"bound": "hbm", "kernel": "backward Riccati sweep (backward_tile16_kernel)",
                                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0] if tr else None,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0].get("backward") if tr else None,
                                "traffic_source": tr[1] if tr else None,
                                "algorithmic_bytes_per_launch": ab["backward"], "avg_launch_us": avg_s * 1e6,
                                "launches": n, "avg_launch_us_back_to_back": bwd_us,
                                "frac_of_measured_copy_peak_6.29TBs": achieved / 6290.0}
             out["phases_us_per_step"] = {k: 1e3 * v[0] / args.steps for k, v in phases.items()}
+            # the same accounting for every hot kernel: algorithmic bytes / its average launch
+            out["kernels"] = {}
+            for ph, kern in PHASE_KERNEL.items():
+                ms_k, n_k = phases[ph]
+                if n_k:
+                    ach = ab[ph] / (ms_k / n_k * 1e-3) / 1e9
+                    out["kernels"][kern] = {"avg_launch_us": ms_k / n_k * 1e3, "launches": n_k,
+                                            "algorithmic_bytes_per_launch": ab[ph], "achieved_GBs": ach,
+                                            "frac_of_8TBs": ach / HBM_PEAK_GBS,
+                                            "traffic": tr[0].get(ph) if tr else None}
         if os.environ.get("ILQR_CLOCK_PROBE"):
             pr = h.get(_lib.PROBE)
             out["clock_probe"] = {"backward_cycles": int(pr[0]), "backward_GHz": float(pr[0]) / max(float(pr[1]), 1) * 0.1,
@@ -252,6 +315,11 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
+            if cpu_all is not None:
+                out["cpu_baseline_all_cores"] = cpu_all
+                out["gpu_over_cpu_all_cores"] = value / cpu_all["value"]
+        if exchange and world == 1:
+            out["exchange"] = "per-step status all-gather over a one-rank RCCL group (side stream)"
         if world == 1 and not args.no_phase_timing and not args.no_solve_extra:
             # reported beside the throughput figure, outside every timed region above: the same batch
             # solved to convergence with the reference's stopping rules (tol, maxiter 50, line-search failure)
@@ -270,8 +338,9 @@ def main():
                 "converged": int(np.sum(stw == _lib.TRAJ_CONVERGED)), "linesearch_failed": int(np.sum(stw == _lib.TRAJ_LINESEARCH_FAILED)),
                 "maxiter": int(np.sum(stw == _lib.TRAJ_MAXITER)), "tol": p["tol"]}
             hs.close()
+            out["mpc_c4_shard"] = mpc_c4_extra(ilqr_amd, _lib, problems, np_dt, local_rank, stream)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.exchange:
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 

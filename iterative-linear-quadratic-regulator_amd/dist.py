@@ -36,8 +36,8 @@ def allreduce_status(stats4, group=None):
     (-min and max share one MAX)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return stats4
+    if not (dist.is_available() and dist.is_initialized()):
+        return stats4      # no process group: a single shard (with a group of ONE rank the collectives still run)
     mm = torch.stack([-stats4[0], stats4[1]])
     dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
     cnt = stats4[2:4].clone()
@@ -88,7 +88,10 @@ class StatusExchange:
             self.done = [None, None]
 
     def launch(self, fill):
-        """fill(stats_tensor) writes this rank's 4-vector on the CURRENT stream (e.g. handle.status_reduce)."""
+        """fill(stats_tensor) writes this rank's 4-vector ON TORCH'S CURRENT STREAM (e.g. handle.status_reduce of a
+        handle created with stream=torch.cuda.current_stream().cuda_stream, as ShardedBatch and bench.py do): the
+        side-stream collective is ordered behind an event recorded on that stream.  A handle that owns a private
+        stream must be synchronised inside `fill` (handle.sync()) before it returns."""
         torch, dist = self.torch, self.dist
         i = self.k & 1
         self.k += 1
@@ -110,9 +113,9 @@ class StatusExchange:
         return i
 
     def _gather(self, i):
-        if self.world == 1:
-            self.gathered[i][0].copy_(self.stats[i])
-        else:
+        if not self.dist.is_initialized():
+            self.gathered[i][0].copy_(self.stats[i])          # no process group at all: a single shard
+        else:                                                  # (a group of ONE rank still goes through RCCL / gloo)
             self.dist.all_gather(list(self.gathered[i].unbind(0)), self.stats[i], group=self.group)
 
     def result(self, i=None) -> GlobalStatus:
@@ -138,9 +141,12 @@ class ShardedBatch:
         self.lo, self.hi = shard_range(len(x0), self.world, self.rank)
         if device is None:
             device = torch.cuda.current_device()
+        # the handle launches on torch's current stream, so torch events / collectives are ordered with its kernels
+        ilqr_kw.setdefault("stream", torch.cuda.current_stream(device).cuda_stream or None)
         self.solver = iLQR(system_factory(), None, x0[self.lo:self.hi], U_init[self.lo:self.hi],
                            device=device, verbose=False, **ilqr_kw)
         self._stats = torch.zeros(4, dtype=torch.float64, device=f"cuda:{device}")
+        self._xchg = None
 
     def solve(self):
         X, U, cost = self.solver.optimize_trajectory()
@@ -154,3 +160,16 @@ class ShardedBatch:
         torch.cuda.synchronize()
         allreduce_status(self._stats)
         return to_status(self._stats.cpu())
+
+    def global_status_async(self) -> GlobalStatus:
+        """The same reduction through the side-stream all-gather (StatusExchange): what bench.py runs per step."""
+        import torch
+        if self._xchg is None:
+            self._xchg = StatusExchange(device=self._stats.device)
+        h = self.solver.handle
+
+        def fill(t):
+            h.status_reduce(t.data_ptr())
+            h.sync()      # also correct for a handle on a private stream
+
+        return self._xchg.result(self._xchg.launch(fill))

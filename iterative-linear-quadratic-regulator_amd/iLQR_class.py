@@ -33,7 +33,7 @@ def horizon_steps(T, dt):
 class iLQR:
     def __init__(self, system: System, T=None, x_0=None, U_init=None, tol=1e-5, maxiter=100,
                  alpha_factor=0.5, min_alpha=1e-8, verbose=True, *, N=None, n_alpha=None, n_trials=10,
-                 dtype=None, device=0, mu=0.0, plant=None, flags=0):
+                 dtype=None, device=0, mu=0.0, plant=None, flags=0, stream=None):
         self.system = system
         self.T = T
         self.tol, self.maxiter = tol, maxiter
@@ -81,7 +81,8 @@ class iLQR:
         self._h = system.make_handle(
             horizon=self.N, batch=self.B, dtype=self.dtype, n_alpha=n_alpha, n_trials=n_trials, tol=tol,
             maxiter=maxiter, alpha_factor=alpha_factor, min_alpha=min_alpha, mu=mu,
-            plant_integrator=None if plant is None else plant.integrator, device=device, flags=flags)
+            plant_integrator=None if plant is None else plant.integrator, device=device, flags=flags,
+            stream=stream)   # stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); None = a private one
         self._h.set_problem(x_0.reshape(self.B, self.n_x), U_init.reshape(self.B, self.n_u, self.N))
         self.status = None
         self.iterations = None
