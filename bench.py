@@ -81,7 +81,7 @@ def numpy_restatement_rate(p, dtype):
     return o.iterations / (time.perf_counter() - t0)
 
 
-def cpu_baseline(p, dtype, cores, budget_s=10.0):
+def cpu_baseline(p, dtype, cores, budget_s=10.0, total_core_seconds=None):
     """The oracle's C restatement of the reference loop (oracle/c/ilqr_oracle.c: per-timestep backward
     and forward passes, SEQUENTIAL backtracking that stops at the first accepted alpha, one trajectory
     per call) on the host cores: a bounded sample of the same workload, one forked worker per core."""
@@ -98,7 +98,10 @@ def cpu_baseline(p, dtype, cores, budget_s=10.0):
     for i in range(8):
         co.solve(x0[i], U0[i], fixed_iters=iters)
     t1 = (time.perf_counter() - t0) / 8
-    per_core = max(8, int(budget_s / max(t1, 1e-6)))
+    if total_core_seconds is not None:     # fixed amount of WORK, spread over `cores` workers (see main)
+        per_core = max(2, int(total_core_seconds / max(t1, 1e-6) / cores))
+    else:
+        per_core = max(8, int(budget_s / max(t1, 1e-6)))
     n_traj = per_core * cores
 
     def work(rank, q):
@@ -172,8 +175,14 @@ def main():
         share, every = host_cores()
         cpu = cpu_baseline(p, args.dtype, share)
         cpu["numpy_restatement_single_core_value"] = numpy_restatement_rate(p, args.dtype)
-        if every > share:      # P = every core the job may run on; the pool may still throttle it to its share
-            cpu_all = cpu_baseline(p, args.dtype, every, budget_s=6.0)
+        if every > share:
+            # P = every core the job may be scheduled on.  The pool gives a 1-GPU job the CPU time of its
+            # share whatever the affinity mask says (round 2: 256 workers ran at 0.44x the 16-worker rate), so this leg
+            # gets a fixed amount of WORK -- as many core-seconds as the share leg -- not a fixed time per worker: a
+            # fraction of a second if the cores are really there, about as long as the share leg if they are not.
+            cpu_all = cpu_baseline(p, args.dtype, every, total_core_seconds=10.0 * share)
+            cpu_all["note"] = ("every core in the affinity mask; the pool throttles a 1-GPU job to its share of the host, so "
+                               "this figure says what the extra workers bought, not what the whole host could do")
 
     import torch
     import torch.distributed as dist
