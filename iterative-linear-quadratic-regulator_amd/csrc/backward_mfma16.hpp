@@ -1,0 +1,352 @@
+// backward_mfma16.hpp -- backward Riccati sweep for n_x = 16, n_u = 8 (BASELINE config c5) on the matrix cores.
+//
+// One wave owns one trajectory, as in backward_wave_kernel, but the value function never leaves the wave's
+// registers and the dense products of iLQR_class.py:100-114 run as v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64
+// (exact f32 / f64 FMA chains, so the rounding is that of an ordinary dot product): this is the one place on the
+// path where n is large enough for MFMA -- a 16 x 16 x 16 product is exactly four instructions.
+//
+// Everything is kept in the instruction's C/D layout ("C-layout"): lane l = 16 g + c holds, in register r, element
+// (row ROW(g, r), column c) of a 16 x 16 matrix, ROW(g, r) = 4 g + r for f32 and g + 4 r for f64.  An MFMA step r fed
+// with register r of two C-layout matrices X, Y as its A and B operands contracts over k = ROW(g, r): the four steps
+// together compute X' Y, whatever the order in which they visit k.  Every product of a Riccati step has that form,
+// with both factors already in C-layout, so no value ever has to be transposed or moved across lanes:
+//     Pt  = V' A                       (= (A'V)' : the reference's left-associated f_x.T @ V_xx)
+//     Qxx = l_xx + Pt' A               (= l_xx + (A'V) A)
+//     Put = V' B ,  Qux = l_ux + Put' A ,  Quu = l_uu + Put' B
+//     V+  = Qxx + Qux' K                           (short form, iLQR_class.py:114)
+// The matrix-vector parts (Q_x = l_x + A'V_x, Q_u = l_u + B'V_x, V_x+ = Q_x + K'Q_u) stay on the vector ALU: an
+// f32-input MFMA runs at only twice a lone wave's vector rate, and a 16-column product for one useful column would
+// put four more 32-cycle instructions on the step's dependent chain.
+// The gain solve [K | k] = -Quu^-1 [Qux | Qu] (:109-110) runs on the vector ALU: the 36 entries of Quu's lower
+// triangle are read to scalars (v_readlane), every lane factors Quu redundantly (Cholesky; rsqrt + Newton), and
+// each lane substitutes one right-hand side -- column c of Qux in lanes 0..31, Q_u in lanes 32..63 -- gathered with
+// ds_bpermute (LDS crossbar, no LDS memory).  If Quu is not positive definite the lanes fall back to LU with partial
+// pivoting, what the reference's solve does unconditionally.
+//
+// mu > 0 (the build's Levenberg extension) and n_x = 8 stay on backward_wave_kernel.
+#pragma once
+#include "kernels.hpp"
+
+namespace ilqr {
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef double f64x4a __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma16;
+template <> struct Mfma16<float> {
+    using acc = f32x4a;
+    static ILQR_DEV constexpr int row(int g, int r) { return 4 * g + r; }
+    static ILQR_DEV constexpr int grp_of(int i) { return i / 4; }   // lane group and register that hold row i
+    static ILQR_DEV constexpr int reg_of(int i) { return i % 4; }
+    static ILQR_DEV acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    static ILQR_DEV float readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+    static ILQR_DEV float bperm(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+};
+template <> struct Mfma16<double> {
+    using acc = f64x4a;
+    static ILQR_DEV constexpr int row(int g, int r) { return g + 4 * r; }
+    static ILQR_DEV constexpr int grp_of(int i) { return i % 4; }
+    static ILQR_DEV constexpr int reg_of(int i) { return i / 4; }
+    static ILQR_DEV acc mma(double a, double b, acc c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    static ILQR_DEV double readlane(double v, int lane) {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+    }
+    static ILQR_DEV double bperm(int byte_addr, double v) {
+        return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)),
+                                __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
+    }
+};
+
+// init + X' Y for two C-layout matrices (four MFMA steps, one dependent chain)
+template <typename T>
+ILQR_DEV typename Mfma16<T>::acc mm_tn(const T* X, const T* Y, typename Mfma16<T>::acc init) {
+    typename Mfma16<T>::acc d = init;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d = Mfma16<T>::mma(X[r], Y[r], d);
+    return d;
+}
+
+// one timestep's expansion: the matrices in C-layout (zero where the (16, 8) blocks are padded to 16 x 16), the two
+// gradient vectors "column-indexed" (lane (g, c) holds entry c)
+template <typename T> struct Tile16x8 {
+    T A[4], Bm[4], lxx[4], lux[4], luu[4], lx, lu;
+};
+
+// Per-lane byte offsets into one expansion record [f_x | f_u | l_x | l_u | l_xx | l_ux | l_uu] and into one gain record
+// [K (8 x 16) | k (8)], fixed for the whole sweep.  ROW(g, r) = ROW(g, 0) + RS r, so register r of a matrix is the
+// lane's offset plus an immediate; a lane whose element lies in the zero padding (or that has nothing to store)
+// carries an offset beyond the record, where a raw buffer load returns 0 and a raw buffer store is dropped
+// (tools/micro/range_probe.hip measured the rule): no selects, no branches, a fixed number of memory operations.
+struct Lane16x8 {
+    int vA, vB, vLux, vLuu, vLx, vLu, vK, vk;
+};
+ILQR_DEV float buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff, float) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+ILQR_DEV double buf_load1(__amdgpu_buffer_rsrc_t r, int voff, int soff, double) {
+    const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+    return __hiloint2double((int)a.y, (int)a.x);
+}
+// 16 bytes: four floats / two doubles
+ILQR_DEV void buf_store16(__amdgpu_buffer_rsrc_t r, int voff, const float* v) {
+    const u32x4 w = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+}
+ILQR_DEV void buf_store16(__amdgpu_buffer_rsrc_t r, int voff, const double* v) {
+    const u32x4 w = {(unsigned)__double2loint(v[0]), (unsigned)__double2hiint(v[0]), (unsigned)__double2loint(v[1]),
+                     (unsigned)__double2hiint(v[1])};
+    __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
+}
+
+template <typename T>
+ILQR_DEV void tile16x8_load(Tile16x8<T>& t, const T* rec, const Lane16x8& o) {
+    using MF = Mfma16<T>;
+    constexpr int NX = 16, NU = 8, S = (int)sizeof(T);
+    constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+    constexpr int oFU = NX * NX, oLX = oFU + NX * NU, oLU = oLX + NX, oLXX = oLU + NU, oLUX = oLXX + NX * NX,
+                  oLUU = oLUX + NU * NX;
+    constexpr int RS = MF::row(0, 1) - MF::row(0, 0);            // row stride between registers: 1 (f32) / 4 (f64)
+    // the descriptor covers exactly this record; `rec` is wave-uniform (block index and loop counter), which make_rsrc
+    // states through readfirstlane -- otherwise hipcc wraps every load in a waterfall loop (cdna_hip_programming.md T20)
+    const __amdgpu_buffer_rsrc_t r = make_rsrc(rec, E * S);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool reg_ok = MF::row(0, q) < NU;                    // f64: registers 2, 3 hold rows >= 8
+        t.A[q] = buf_load1(r, o.vA + S * NX * RS * q, 0, T(0));
+        t.lxx[q] = buf_load1(r, o.vA + S * NX * RS * q, S * oLXX, T(0));
+        t.Bm[q] = buf_load1(r, o.vB + S * NU * RS * q, S * oFU, T(0));
+        t.lux[q] = reg_ok ? buf_load1(r, o.vLux + S * NX * RS * q, S * oLUX, T(0)) : T(0);
+        t.luu[q] = reg_ok ? buf_load1(r, o.vLuu + S * NU * RS * q, S * oLUU, T(0)) : T(0);
+    }
+    t.lx = buf_load1(r, o.vLx, S * oLX, T(0));
+    t.lu = buf_load1(r, o.vLu, S * oLU, T(0));
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
+    using MF = Mfma16<T>;
+    using acc = typename MF::acc;
+    constexpr int NX = 16, NU = 8, S = (int)sizeof(T);
+    constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+    constexpr int R = gain_record(NX, NU);
+    constexpr int RS = MF::row(0, 1) - MF::row(0, 0);
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int st = a.status[b];
+    if (!traj_active(st)) return;
+    const size_t B = a.B;
+    const int N = a.N;
+
+    // terminal condition (iLQR_class.py:136-138): V in C-layout; V_x "row-indexed" (register r of lane (g, .) holds
+    // entry ROW(g, r): the B operand of a product with a matrix of 16 equal columns)
+    T V[4], Vx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = MF::row(g, r);
+        V[r] = a.term[(size_t)(NX + row * NX + c) * B + b];
+        Vx[r] = a.term[(size_t)row * B + b];
+    }
+    const T* __restrict__ lin = a.lin + (size_t)b * E;
+    const size_t tstride = B * E;
+    Lane16x8 off;
+    constexpr int kBeyond = 0x7ffffff0;
+    const int row0 = MF::row(g, 0);
+    const bool lane_ok = row0 < NU;                                // f32: lane groups 2, 3 only hold rows >= 8
+    off.vA = S * (NX * row0 + c);
+    off.vB = c < NU ? S * (NU * row0 + c) : kBeyond;
+    off.vLux = lane_ok ? S * (NX * row0 + c) : kBeyond;
+    off.vLuu = (lane_ok && c < NU) ? S * (NU * row0 + c) : kBeyond;
+    off.vLx = S * c;
+    off.vLu = c < NU ? S * c : kBeyond;
+    off.vK = lane_ok ? S * (NX * row0 + c) : kBeyond;            // K[ROW(g, r)][c] (rows < 8)
+    off.vk = lane == 32 ? S * NU * NX : kBeyond;                 // k: one lane of the half that solved for it
+    // cross-lane addresses (ds_bpermute: byte address = 4 * source lane), fixed for the whole sweep
+    const int a16 = 4 * (lane ^ 16), a32 = 4 * (lane ^ 32);
+    int aRow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) aRow[r] = 4 * MF::row(g, r);       // lane (0, ROW(g, r)): column-indexed -> row-indexed
+
+    Tile16x8<T> cur, nxt;
+    tile16x8_load(cur, lin + (size_t)(N - 1) * tstride, off);
+    bool all_pd = true;
+    const acc zero = {T(0), T(0), T(0), T(0)};
+    auto arr = [](const acc& v, T* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; };
+    auto vec = [](const T* v) { acc o = {v[0], v[1], v[2], v[3]}; return o; };
+    // sum over the four lane groups: every lane (., c) ends with the total of column c
+    auto group_sum = [&](T v) { v += MF::bperm(a16, v); v += MF::bperm(a32, v); return v; };
+
+    for (int t = N - 1; t >= 0; --t) {
+        // the next step's expansion does not depend on the carried value function: request it now
+        tile16x8_load(nxt, lin + (size_t)(t > 0 ? t - 1 : 0) * tstride, off);
+
+        // ---- Q-function (iLQR_class.py:100-104) ---------------------------------------------------------------
+        // An f32 16x16x16 product is four 32-cycle MFMAs (the f32-input matrix rate is only twice a lone wave's
+        // vector rate), so the matrix pipe is kept for the six matrix-matrix products and everything vector-shaped
+        // stays on the vector ALU, which would otherwise idle behind the dependent MFMA chains.
+        T Put[4], Pt[4], Quu[4], Qux[4], Qxx[4];
+        {
+            // (B'V)' first: the gain solve waits for this chain.  Two accumulators halve its dependent latency.
+            acc d0 = zero, d1 = zero;
+            d0 = MF::mma(V[0], cur.Bm[0], d0);
+            d1 = MF::mma(V[1], cur.Bm[1], d1);
+            d0 = MF::mma(V[2], cur.Bm[2], d0);
+            d1 = MF::mma(V[3], cur.Bm[3], d1);
+            arr(d0 + d1, Put);
+        }
+        // Q_u = l_u + B'V_x and Q_x = l_x + A'V_x, column-indexed: 4 products per lane, summed over the lane groups
+        T qu_c = T(0), qx_c = T(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            qu_c += cur.Bm[r] * Vx[r];
+            qx_c += cur.A[r] * Vx[r];
+        }
+        qu_c = cur.lu + group_sum(qu_c);
+        qx_c = cur.lx + group_sum(qx_c);
+        {
+            acc dQuu = vec(cur.luu), dQux = vec(cur.lux);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dQuu = MF::mma(Put[r], cur.Bm[r], dQuu);
+                dQux = MF::mma(Put[r], cur.A[r], dQux);
+            }
+            arr(dQuu, Quu);
+            arr(dQux, Qux);
+        }
+        // (A'V)' and Q_xx: independent of the solve, they run on the matrix pipe beside the factorisation
+        arr(mm_tn<T>(V, cur.A, zero), Pt);
+        arr(mm_tn<T>(Pt, cur.A, vec(cur.lxx)), Qxx);
+
+        // ---- gain solve (:109-110) ---------------------------------------------------------------------------------
+        // Quu's lower triangle and Q_u to scalars: row i of Quu lives in lane group grp_of(i), register reg_of(i)
+        T q[NU][NU], qu[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) q[i][j] = MF::readlane(Quu[MF::reg_of(i)], 16 * MF::grp_of(i) + j);
+            qu[i] = MF::readlane(qu_c, i);
+        }
+        // this lane's right-hand side: column c of Q_ux (lanes 0..31, both halves solve the same 16 columns) or Q_u
+        T rhs[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const T col = MF::bperm(4 * (16 * MF::grp_of(i) + c), Qux[MF::reg_of(i)]);
+            rhs[i] = g < 2 ? col : qu[i];
+        }
+        // Cholesky Quu = L L', redundantly in every lane (all operands are wave-uniform); Li[c] = 1 / L[c][c]
+        T L[NU][NU], Li[NU];
+        bool pd = true;
+#pragma unroll
+        for (int cc = 0; cc < NU; ++cc) {
+            T d = q[cc][cc];
+#pragma unroll
+            for (int s = 0; s < cc; ++s) d -= L[cc][s] * L[cc][s];
+            pd = pd && (d > T(0));
+            const T inv = fast_rsqrt(pd ? d : T(1));
+            L[cc][cc] = d * inv;
+            Li[cc] = inv;
+#pragma unroll
+            for (int i = cc + 1; i < NU; ++i) {
+                T v = q[i][cc];
+#pragma unroll
+                for (int s = 0; s < cc; ++s) v -= L[i][s] * L[cc][s];
+                L[i][cc] = v * inv;
+            }
+        }
+        all_pd = all_pd && pd;
+        T y[NU];
+        if (pd) {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {             // L y = rhs
+                T v = rhs[i];
+#pragma unroll
+                for (int s = 0; s < i; ++s) v -= L[i][s] * y[s];
+                y[i] = v * Li[i];
+            }
+#pragma unroll
+            for (int i = NU - 1; i >= 0; --i) {        // L' z = y
+                T v = y[i];
+#pragma unroll
+                for (int s = i + 1; s < NU; ++s) v -= L[s][i] * y[s];
+                y[i] = v * Li[i];
+            }
+        } else {
+            // not positive definite: Gaussian elimination with partial pivoting on the full matrix, what the reference's
+            // jnp.linalg.solve always does (iLQR_class.py:109-110); rare, so the upper triangle is only fetched here
+            T Ac[NU][NU], rr[NU][1];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+#pragma unroll
+                for (int j = 0; j < NU; ++j)
+                    Ac[i][j] = j <= i ? q[i][j] : MF::readlane(Quu[MF::reg_of(i)], 16 * MF::grp_of(i) + j);
+                rr[i][0] = rhs[i];
+            }
+            lu_solve_inplace<T, NU, 1>(Ac, rr);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) y[i] = rr[i][0];
+        }
+        // y = Quu^-1 rhs: lanes 0..31 hold column c of -K, lanes 32..63 hold -k
+
+        // V_x+ = Q_x + K'Q_u (:113), column-indexed in the lanes that solved a column of K, then row-indexed for the
+        // next step: register r of lane (g, .) <- entry ROW(g, r), held by lane (0, ROW(g, r))
+        T vxn = qx_c;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) vxn -= y[i] * qu[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Vx[r] = MF::bperm(aRow[r], vxn);
+
+        // K in C-layout (rows >= 8 of the padded matrix are zero): lane (g, c) register r <- K[ROW(g, r)][c]
+        T K[4];
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) K[r] = g == 0 ? -y[r] : (g == 1 ? -y[4 + r] : T(0));
+        } else {
+            // f64: every lane group holds rows g, g + 4 (registers 0, 1); lane groups 2, 3 solved Q_u, so they fetch
+            // their two entries of column c from a lane that solved it
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                T pick = T(0);
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const T cand = MF::bperm(4 * (16 * (gg & 1) + c), -y[MF::row(gg, r)]);
+                    pick = g == gg ? cand : pick;
+                }
+                K[r] = pick;
+            }
+            K[2] = T(0);
+            K[3] = T(0);
+        }
+
+        // ---- gains out: K_t row-major [8][16], then k_t [8]; lanes with nothing to store carry a dropped offset ------
+        {
+            const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gains + ((size_t)t * B + b) * R, R * S);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (MF::row(0, r) < NU) {
+                    if constexpr (sizeof(T) == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(K[r]), rg, off.vK + S * NX * RS * r, 0, 0);
+                    else buf_store1(rg, off.vK + S * NX * RS * r, 0, K[r]);
+                }
+            T kk[NU];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) kk[i] = -y[i];
+#pragma unroll
+            for (int i = 0; i < NU; i += 16 / S) buf_store16(rg, off.vk + S * i, kk + i);
+        }
+
+        // ---- V+ = Q_xx + Q_ux' K (:114); two accumulators: the next step's first product waits for it -------------------
+        {
+            acc d0 = vec(Qxx), d1 = zero;
+            d0 = MF::mma(Qux[0], K[0], d0);
+            d1 = MF::mma(Qux[1], K[1], d1);
+            if constexpr (sizeof(T) == 4) {        // (f64: registers 2, 3 of K are rows >= 8: nothing to add)
+                d0 = MF::mma(Qux[2], K[2], d0);
+                d1 = MF::mma(Qux[3], K[3], d1);
+            }
+            arr(d0 + d1, V);
+        }
+        cur = nxt;
+    }
+    if (lane == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
+}
+
+}  // namespace ilqr

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kernels_wave.hpp"
+#include "backward_mfma16.hpp"
 
 namespace ilqr {
 
@@ -242,6 +243,14 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
         };
     }
     o.backward = [](const KArgs<T>& a, hipStream_t s) {
+        if constexpr (NX == 16 && NU == 8) {
+            // the (16, 8) sweep runs on the matrix cores (backward_mfma16.hpp); mu > 0 keeps the LDS form
+            static const bool lds_form = getenv("ILQR_BACKWARD_WAVE_LDS") != nullptr;   // A/B switch
+            if (a.mu == T(0) && !lds_form) {
+                ILQR_LAUNCH((backward_mfma16_kernel<T>), dim3(a.B), dim3(64), 0, s, a);
+                return;
+            }
+        }
         ILQR_LAUNCH((backward_wave_kernel<T, NX, NU>), dim3(a.B), dim3(64), 0, s, a);
     };
     o.eval = [](const EvalArgs<T>& a, hipStream_t s) {

@@ -37,9 +37,10 @@ def _solve_with_trace(h, iters):
     cost_prev = cost.copy()
     for _ in range(iters):
         before = cost
+        running = (h.get(_lib.STATUS) & 0xff) == 0          # a finished trajectory is frozen, its alpha_taken too
         h.iterate(1)
         cost = h.get(_lib.COST).astype(np.float64)
-        took = h.get(_lib.ALPHA) > 0
+        took = running & (h.get(_lib.ALPHA) > 0)
         cost_prev = np.where(took, before, cost_prev)
     return cost, cost_prev, h.get(_lib.STATUS)
 
