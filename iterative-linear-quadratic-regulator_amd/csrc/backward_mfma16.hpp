@@ -41,6 +41,25 @@ template <> struct Mfma16<float> {
     static ILQR_DEV acc mma(float a, float b, acc c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
     static ILQR_DEV float readlane(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
     static ILQR_DEV float bperm(int byte_addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v))); }
+    // v_permlane16_swap / v_permlane32_swap (gfx950) exchange 16- / 32-lane halves on the vector ALU: no LDS-crossbar round
+    // trip (~120 cycles each for ds_bpermute, which a lone wave cannot hide).  swap16(v): {lower row's value, upper
+    // row's value} of every pair of 16-lane rows, in both rows; swap32(v): the same for the two 32-lane halves.
+    static ILQR_DEV void swap16(float v, float& lo, float& hi) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+    }
+    static ILQR_DEV void swap32(float v, float& lo, float& hi) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        lo = __uint_as_float(r[0]); hi = __uint_as_float(r[1]);
+    }
+    // sum over the four lane groups (g = 0..3), result in every lane
+    static ILQR_DEV float group_sum(float v, int, int) {
+        float a, b;
+        swap16(v, a, b);
+        v = a + b;
+        swap32(v, a, b);
+        return a + b;
+    }
 };
 template <> struct Mfma16<double> {
     using acc = f64x4a;
@@ -54,6 +73,11 @@ template <> struct Mfma16<double> {
     static ILQR_DEV double bperm(int byte_addr, double v) {
         return __hiloint2double(__builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v)),
                                 __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v)));
+    }
+    static ILQR_DEV double group_sum(double v, int a16, int a32) {   // (f64 keeps the LDS-crossbar form)
+        v += bperm(a16, v);
+        v += bperm(a32, v);
+        return v;
     }
 };
 
@@ -122,6 +146,22 @@ ILQR_DEV void tile16x8_load(Tile16x8<T>& t, const T* rec, const Lane16x8& o) {
     t.lu = buf_load1(r, o.vLu, S * oLU, T(0));
 }
 
+// Diagnostic build only (-DILQR_MFMA16_STAMPS, tools/c5_stamps.py): s_memtime at the phase boundaries of a step, summed
+// over the sweep by workgroup 0 and written to the probe buffer (values nothing else reads).  ILQR_STAMP(k, v) issues a
+// v_mov of `v` first, so the stamp is taken once `v` is available (a lone wave issues in order).
+#ifdef ILQR_MFMA16_STAMPS
+#define ILQR_STAMP(k, v)                                                                  \
+    do {                                                                                  \
+        float sink_;                                                                      \
+        asm volatile("v_mov_b32 %0, %1" : "=v"(sink_) : "v"((float)(v)));                 \
+        const long long now_ = __builtin_readcyclecounter();                              \
+        stamp_acc[k] += now_ - stamp_last;                                                \
+        stamp_last = now_;                                                                \
+    } while (0)
+#else
+#define ILQR_STAMP(k, v) do {} while (0)
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
     using MF = Mfma16<T>;
@@ -169,31 +209,58 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
 
     Tile16x8<T> cur, nxt;
     tile16x8_load(cur, lin + (size_t)(N - 1) * tstride, off);
+    {
+        // Every load of the prologue (first tile, terminal value function) is consumed here, before the loop: hipcc's s_waitcnt bookkeeping then enters the
+        // loop with nothing pending.  Otherwise the loop header merges "22 loads pending" (from here) with "22 loads and
+        // the 6 gain stores behind them pending" (from the back edge) into the tighter of the two counts, and every step
+        // waits for the previous step's STORES to complete before it may touch its tile (measured: 17 % of the sweep).
+        T touch = cur.lx + cur.lu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) touch += cur.A[r] + cur.Bm[r] + cur.lxx[r] + cur.lux[r] + cur.luu[r] + V[r] + Vx[r];
+        asm volatile("" ::"v"(touch));
+    }
     bool all_pd = true;
+#ifdef ILQR_MFMA16_STAMPS
+    long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long stamp_last = __builtin_readcyclecounter();
+#endif
     const acc zero = {T(0), T(0), T(0), T(0)};
     auto arr = [](const acc& v, T* o) { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; };
     auto vec = [](const T* v) { acc o = {v[0], v[1], v[2], v[3]}; return o; };
     // sum over the four lane groups: every lane (., c) ends with the total of column c
-    auto group_sum = [&](T v) { v += MF::bperm(a16, v); v += MF::bperm(a32, v); return v; };
+    auto group_sum = [&](T v) { return MF::group_sum(v, a16, a32); };
 
     for (int t = N - 1; t >= 0; --t) {
         // the next step's expansion does not depend on the carried value function: request it now
         tile16x8_load(nxt, lin + (size_t)(t > 0 ? t - 1 : 0) * tstride, off);
+        ILQR_STAMP(8, off.vA);
+        ILQR_STAMP(9, cur.Bm[0] + cur.A[3] + cur.lu + V[0]);
 
         // ---- Q-function (iLQR_class.py:100-104) ---------------------------------------------------------------
         // An f32 16x16x16 product is four 32-cycle MFMAs (the f32-input matrix rate is only twice a lone wave's
         // vector rate), so the matrix pipe is kept for the six matrix-matrix products and everything vector-shaped
         // stays on the vector ALU, which would otherwise idle behind the dependent MFMA chains.
         T Put[4], Pt[4], Quu[4], Qux[4], Qxx[4];
+        // MFMA issue order is pinned (ILQR_MFMA_NEXT = a scheduling barrier behind every instruction): left alone, hipcc
+        // issues each product's four dependent instructions back to back (40 cycles of latency each, measured: ~1100 of a
+        // step's ~3500 cycles in front of the factorisation); round-robin over independent chains the pipe takes one
+        // every 32 cycles.
+#define ILQR_MFMA_NEXT() __builtin_amdgcn_sched_barrier(0)
         {
-            // (B'V)' first: the gain solve waits for this chain.  Two accumulators halve its dependent latency.
-            acc d0 = zero, d1 = zero;
-            d0 = MF::mma(V[0], cur.Bm[0], d0);
-            d1 = MF::mma(V[1], cur.Bm[1], d1);
-            d0 = MF::mma(V[2], cur.Bm[2], d0);
-            d1 = MF::mma(V[3], cur.Bm[3], d1);
-            arr(d0 + d1, Put);
+            // (B'V)' and (A'V)', two accumulators each
+            acc p0 = zero, p1 = zero, t0 = zero, t1 = zero;
+            p0 = MF::mma(V[0], cur.Bm[0], p0); ILQR_MFMA_NEXT();
+            t0 = MF::mma(V[0], cur.A[0], t0); ILQR_MFMA_NEXT();
+            p1 = MF::mma(V[1], cur.Bm[1], p1); ILQR_MFMA_NEXT();
+            t1 = MF::mma(V[1], cur.A[1], t1); ILQR_MFMA_NEXT();
+            p0 = MF::mma(V[2], cur.Bm[2], p0); ILQR_MFMA_NEXT();
+            t0 = MF::mma(V[2], cur.A[2], t0); ILQR_MFMA_NEXT();
+            p1 = MF::mma(V[3], cur.Bm[3], p1); ILQR_MFMA_NEXT();
+            t1 = MF::mma(V[3], cur.A[3], t1); ILQR_MFMA_NEXT();
+            arr(p0 + p1, Put);
+            arr(t0 + t1, Pt);
         }
+        ILQR_STAMP(0, Put[0]);
         // Q_u = l_u + B'V_x and Q_x = l_x + A'V_x, column-indexed: 4 products per lane, summed over the lane groups
         T qu_c = T(0), qx_c = T(0);
 #pragma unroll
@@ -204,18 +271,27 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
         qu_c = cur.lu + group_sum(qu_c);
         qx_c = cur.lx + group_sum(qx_c);
         {
-            acc dQuu = vec(cur.luu), dQux = vec(cur.lux);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dQuu = MF::mma(Put[r], cur.Bm[r], dQuu);
-                dQux = MF::mma(Put[r], cur.A[r], dQux);
-            }
-            arr(dQuu, Quu);
-            arr(dQux, Qux);
+            // Q_uu (the factorisation waits for it: two accumulators), Q_ux, Q_xx round-robin
+            acc u0 = vec(cur.luu), u1 = zero, x = vec(cur.lux), y2 = vec(cur.lxx);
+            u0 = MF::mma(Put[0], cur.Bm[0], u0); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[0], cur.A[0], x); ILQR_MFMA_NEXT();
+            u1 = MF::mma(Put[1], cur.Bm[1], u1); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[0], cur.A[0], y2); ILQR_MFMA_NEXT();
+            u0 = MF::mma(Put[2], cur.Bm[2], u0); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[1], cur.A[1], x); ILQR_MFMA_NEXT();
+            u1 = MF::mma(Put[3], cur.Bm[3], u1); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[1], cur.A[1], y2); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[2], cur.A[2], x); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[2], cur.A[2], y2); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[3], cur.A[3], x); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[3], cur.A[3], y2); ILQR_MFMA_NEXT();
+            arr(u0 + u1, Quu);
+            arr(x, Qux);
+            arr(y2, Qxx);
         }
-        // (A'V)' and Q_xx: independent of the solve, they run on the matrix pipe beside the factorisation
-        arr(mm_tn<T>(V, cur.A, zero), Pt);
-        arr(mm_tn<T>(Pt, cur.A, vec(cur.lxx)), Qxx);
+#undef ILQR_MFMA_NEXT
+        ILQR_STAMP(1, Quu[0] + Qux[0]);
+        ILQR_STAMP(2, Qxx[0] + qu_c + qx_c);
 
         // ---- gain solve (:109-110) ---------------------------------------------------------------------------------
         // Quu's lower triangle and Q_u to scalars: row i of Quu lives in lane group grp_of(i), register reg_of(i)
@@ -228,11 +304,24 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
         }
         // this lane's right-hand side: column c of Q_ux (lanes 0..31, both halves solve the same 16 columns) or Q_u
         T rhs[NU];
+        if constexpr (sizeof(T) == 4) {
+            // f32: rows 0-3 of column c sit in lane (0, c), rows 4-7 in lane (1, c): one 16-lane swap per register
+            // gives both lanes the whole column
 #pragma unroll
-        for (int i = 0; i < NU; ++i) {
-            const T col = MF::bperm(4 * (16 * MF::grp_of(i) + c), Qux[MF::reg_of(i)]);
-            rhs[i] = g < 2 ? col : qu[i];
+            for (int r = 0; r < 4; ++r) {
+                T lo, hi;
+                MF::swap16(Qux[r], lo, hi);
+                rhs[r] = g < 2 ? lo : qu[r];
+                rhs[4 + r] = g < 2 ? hi : qu[4 + r];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                const T col = MF::bperm(4 * (16 * MF::grp_of(i) + c), Qux[MF::reg_of(i)]);
+                rhs[i] = g < 2 ? col : qu[i];
+            }
         }
+        ILQR_STAMP(3, rhs[0] + rhs[7] + q[7][7]);
         // Cholesky Quu = L L', redundantly in every lane (all operands are wave-uniform); Li[c] = 1 / L[c][c]
         T L[NU][NU], Li[NU];
         bool pd = true;
@@ -254,6 +343,7 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
             }
         }
         all_pd = all_pd && pd;
+        ILQR_STAMP(4, Li[7]);
         T y[NU];
         if (pd) {
 #pragma unroll
@@ -286,6 +376,7 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
             for (int i = 0; i < NU; ++i) y[i] = rr[i][0];
         }
         // y = Quu^-1 rhs: lanes 0..31 hold column c of -K, lanes 32..63 hold -k
+        ILQR_STAMP(5, y[0]);
 
         // V_x+ = Q_x + K'Q_u (:113), column-indexed in the lanes that solved a column of K, then row-indexed for the
         // next step: register r of lane (g, .) <- entry ROW(g, r), held by lane (0, ROW(g, r))
@@ -344,8 +435,16 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
             }
             arr(d0 + d1, V);
         }
+        ILQR_STAMP(6, V[0] + Vx[0]);
         cur = nxt;
+        ILQR_STAMP(7, cur.A[0]);
     }
+#ifdef ILQR_MFMA16_STAMPS
+    if (a.probe && blockIdx.x == 0 && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) a.probe[8 + k] = stamp_acc[k];
+    }
+#endif
     if (lane == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
 }
 
