@@ -24,6 +24,7 @@
 // kept in flight in registers (D*5 loads per lane outstanding) so HBM latency hides under compute.
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "dynamics.hpp"
 
@@ -150,6 +151,32 @@ ILQR_DEV void tile16_load_buf(Tile16<T>& tl, __amdgpu_buffer_rsrc_t r, const Til
     tl.luxi = BufLoad<34, T>::v1(r, o.vi, soff);   // l_ux[i]
 }
 
+// ---- the fp32 tile as the un-regularised fp32 step takes it ---------------------------------------------------
+// What bounds the fp32 sweep is neither HBM nor the wave's own instruction stream but the CU's vector-memory RETURN
+// path: 64 B/clk, shared by the four waves (tools/micro/issue_rate.hip: a 16-byte-per-lane load costs a lone wave
+// 16 cycles and four waves 64).  A lane (i, j) needs 15 of the tile's 48 scalars, and loading each of them into every
+// lane that needs it -- 17 dwords per lane and step -- kept that path busy for 4 waves x 17 x 4 = 272 of the step's
+// ~385 cycles.  The scalars that depend only on the ROW i (SK[i][0..3], f_u[i], l_ux[i]) are the same in the four lanes
+// of a quad, so here each lane loads ONE element of them (a = tile[l16] = SK[i][j], c = tile[32 + l16]: lane (i, 0) gets
+// f_u[i], lane (i, 2) gets l_ux[i]) and the quad shares them by DPP broadcast (quad_perm:[d,d,d,d]), folded into the
+// consuming instruction where that instruction has no other lane move, else a v_mov_b32_dpp the wave has issue slots to
+// spare for: 11 dwords per lane and step, 4 more VALU instructions.  The column-dependent scalars (SK[j][..], f_u[j] ...)
+// sit in lanes 4 apart, where no DPP pattern is a broadcast; they stay replicated loads.
+struct TileQ {
+    float skj[4];  // SK[j][0..3]
+    float vj[4];   // f_u[j], l_x[j], l_ux[j], e_j
+    float a;       // SK[i][j]: the quad holds SK[i][0..3]
+    float lxx;     // l_xx[i][j]
+    float c;       // tile[32 + 4i + j]: f_u[i] on lane j = 0, l_ux[i] on lane j = 2
+};
+ILQR_DEV void tileq_load_buf(TileQ& tl, __amdgpu_buffer_rsrc_t r, const TileOffsets& o, int soff) {
+    BufLoad<0, float>::v4(r, o.vj, soff, tl.skj);
+    BufLoad<32, float>::v4(r, o.vj, soff, tl.vj);
+    tl.a = BufLoad<0, float>::v1(r, o.vl, soff);
+    tl.lxx = BufLoad<16, float>::v1(r, o.vl, soff);
+    tl.c = BufLoad<32, float>::v1(r, o.vl, soff);
+}
+
 // ---- tile loads hipcc does not count -------------------------------------------------------------------
 // hipcc places its own s_waitcnt for loads it can see, and at a loop edge it drains them all (measured:
 // vmcnt(0..5) at the top of every ring pass = one exposed memory latency per D steps; with the tiles coming
@@ -176,6 +203,14 @@ ILQR_DEV i32x4 make_srd(const void* base, unsigned bytes) {
     d.z = uniform((int)bytes);
     d.w = 0x00020000;
     return d;
+}
+
+template <int... I, typename F> ILQR_DEV void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): an unrolled loop whose index is a constant expression
+template <int N, typename F> ILQR_DEV void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
 template <typename T> struct RawTile;
@@ -255,6 +290,45 @@ template <> struct RawTile<double> {
         t.skj[0] = skj0.x; t.skj[1] = skj0.y; t.skj[2] = skj1.x; t.skj[3] = skj1.y;
         t.vj[0] = vj0.x; t.vj[1] = vj0.y; t.vj[2] = vj1.x; t.vj[3] = vj1.y;
         t.lxx = lxx; t.bi = bi; t.luxi = 0.0;   // (row-form l_ux is only used by the fp32 step)
+    }
+};
+
+// The quad-shared fp32 tile (TileQ) in the ring: two 16-byte and three 4-byte loads per lane.  issue<true>() is the
+// prologue's combined form; issue_part<K>() is ONE load of a refill as its own statement, for the step that spreads the
+// refill of the previous slot over its own arithmetic (tile16_step_f32<true>).  Part 0 carries the s_nop 4 of the
+// combined form: all five parts read the same descriptor / soffset SGPRs, which are therefore materialised before it.
+struct RawTileQ {
+    static constexpr int NLOAD = 5;
+    f32x4n skj, vj;
+    float a, lxx, c;
+    ILQR_DEV void issue_first(const i32x4& srd, const TileOffsets& o, int soff) {
+        asm volatile(
+            "s_nop 4\n\t"
+            "buffer_load_dwordx4 %0, %5, %7, %8 offen" ILQR_TILE_NT "\n\t"
+            "buffer_load_dwordx4 %1, %5, %7, %8 offen offset:128" ILQR_TILE_NT "\n\t"
+            "buffer_load_dword %2, %6, %7, %8 offen" ILQR_TILE_NT "\n\t"
+            "buffer_load_dword %3, %6, %7, %8 offen offset:64" ILQR_TILE_NT "\n\t"
+            "buffer_load_dword %4, %6, %7, %8 offen offset:128" ILQR_TILE_NT
+            : "=&v"(skj), "=&v"(vj), "=&v"(a), "=&v"(lxx), "=&v"(c)
+            : "v"(o.vj), "v"(o.vl), "s"(srd), "s"(soff)
+            : "memory");
+    }
+#define ILQR_RAWTILE_PART(NOP, dst, voff, IMM)                                                               \
+    asm volatile(NOP "buffer_load_dword" IMM ILQR_TILE_NT : "+&v"(dst) : "v"(voff), "s"(srd), "s"(soff) : "memory")
+    template <int K> ILQR_DEV void issue_part(const i32x4& srd, const TileOffsets& o, int soff) {
+        if constexpr (K == 0) ILQR_RAWTILE_PART("s_nop 4\n\t", skj, o.vj, "x4 %0, %1, %2, %3 offen");
+        if constexpr (K == 1) ILQR_RAWTILE_PART("", vj, o.vj, "x4 %0, %1, %2, %3 offen offset:128");
+        if constexpr (K == 2) ILQR_RAWTILE_PART("", a, o.vl, " %0, %1, %2, %3 offen");
+        if constexpr (K == 3) ILQR_RAWTILE_PART("", lxx, o.vl, " %0, %1, %2, %3 offen offset:64");
+        if constexpr (K == 4) ILQR_RAWTILE_PART("", c, o.vl, " %0, %1, %2, %3 offen offset:128");
+    }
+    template <int N> ILQR_DEV void wait() {
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(skj), "+v"(vj), "+v"(a), "+v"(lxx), "+v"(c) : "i"(N) : "memory");
+    }
+    ILQR_DEV void unpack(TileQ& t) const {
+        t.skj[0] = skj.x; t.skj[1] = skj.y; t.skj[2] = skj.z; t.skj[3] = skj.w;
+        t.vj[0] = vj.x; t.vj[1] = vj.y; t.vj[2] = vj.z; t.vj[3] = vj.w;
+        t.a = a; t.lxx = lxx; t.c = c;
     }
 };
 
@@ -384,81 +458,117 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
 }
 
 // ---- fp32 step with a hand-ordered instruction stream ---------------------------------------------------
-// The three chains of a step -- (A) P -> Q_xx, (B) pu -> Q_ux, Q_uu, (C) Q_x, Q_u -- are independent until
-// the gain solve.  A lone wave issues an independent instruction every ~4 cycles but a dependent one only
-// every ~6.5-8, and a DPP read needs 2 wait states behind its producer; hipcc's order left the sweep at
-// ~6.5 cycles/instruction.  Here the first 27 instructions are volatile asm statements (never reordered
-// among themselves) written round-robin over the chains, so every operand was produced >= 3 instructions
-// earlier: no s_nop, no dependent-issue bubble.  The short serial tail (reciprocal, gains, transpose,
-// value update) stays in C++ where hipcc pads the transcendental / LDS-crossbar hazards itself.
-#define ILQR_V_MUL(d, a, b) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b))
-#define ILQR_V_FMA(d, a, b, c) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
-#define ILQR_V_FMAC(acc, a, b) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "v"(a), "v"(b))
-#define ILQR_V_ADD_DPP(d, a, CTRL)                                                              \
-    asm volatile("v_add_f32_dpp %0, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(a))
+// The chains of a step -- (A) P -> Q_xx, (B) pu -> Q_ux, (R) the same in row form, (C) Q_x, (C2) Q_u,
+// (Q) Q_uu -> 1/Q_uu -- are independent until the gain.  A lone wave (the batch puts one wave on each SIMD) issues
+// an independent VALU instruction every ~5.4 cycles but a dependent one only every ~8.8, a dependent DPP read
+// needs two more wait states, and v_rcp_f32 costs 9 (12.5 dependent) -- tools/micro/issue_rate.hip.  hipcc's
+// order left the sweep at ~6.5 cycles/instruction; here the 37 instructions up to the reciprocal are volatile asm
+// statements (never reordered among themselves) written round-robin over the chains, so that every operand was
+// produced >= 3 instructions earlier: no s_nop, no dependent-issue bubble.  Q_uu is finished EARLY (27) and its
+// reciprocal issued at 31, so the transcendental's latency hides under the last four contraction terms instead of
+// heading the serial tail; the tail left to hipcc is K, k, V_xx, V_x: two dependent instructions deep.
+//
+// Chain R computes Q_ux a second time in ROW form (lane (i, j) holds Q_ux[i]) instead of transposing the column
+// form through the LDS crossbar at the end of the step (ds_bpermute + lgkmcnt wait sat on the critical path: ~68
+// cycles).  Row form needs pu[i] = sum_k f_u[k] V_xx[k][i] along the ROW, i.e. it reads V_xx[i][k] for V_xx[k][i]:
+// V_xx is symmetric up to the rounding of its own update, so the two forms agree to an ulp-sized perturbation of
+// V_xx (the reference does not symmetrise either).
+//
+// 1/Q_uu keeps its Newton step (without it the fp32 solve parts from the fp32 oracle's alpha sequence at iterations
+// where the cost still moves by 2e-3, against 2e-4 with it -- tests/test_gpu_fullshape.py), but as instructions 34
+// and 37 of the block, not as two dependent instructions of the tail.
+//
+// The statement is cut in five, and with REFILL one load of the PREVIOUS slot's refill sits in each cut (that slot
+// was consumed one step earlier: its registers are dead).  A vector-memory instruction of a lone wave is not free
+// -- the wave issues in order and a 16-byte-per-lane load holds it ~16 cycles whether or not ALU work follows
+// (issue_rate: 8 loads + 56 FMAs = 8 x 54 cycles, the sum of both) -- so spreading the loads does not hide their
+// issue; it lets each load's address phase start earlier and measured 0.3-0.8 us (1-2 %) better than issuing the
+// five back to back behind the step.
 #define ILQR_QP1 "quad_perm:[1,2,3,0]"
 #define ILQR_QP2 "quad_perm:[2,3,0,1]"
 #define ILQR_QP3 "quad_perm:[3,0,1,2]"
 #define ILQR_QSW "quad_perm:[1,0,3,2]"
-
-ILQR_DEV void tile16_step_f32(const Tile16<float>& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj,
-                              float& kff, bool& pd) {
-    // Chain R computes Q_ux a second time in ROW form (lane (i, j) holds Q_ux[i]) instead of transposing the
-    // column form through the LDS crossbar at the end of the step (ds_bpermute + lgkmcnt wait sat on the critical
-    // path: ~50 cycles of a ~390-cycle step).  Row form needs pu[i] = sum_k f_u[k] V_xx[k][i] along the ROW, i.e.
-    // it reads V_xx[i][k] for V_xx[k][i]: V_xx is symmetric up to the rounding of its own update, so the two forms
-    // agree to an ulp-sized perturbation of V_xx (the reference does not symmetrise either).  Seven more
-    // instructions, all off the critical path, against one LDS round trip on it.
-    // The 34 instructions are ONE asm statement: between separate statements hipcc's hazard recogniser, which
-    // cannot see inside them, put a defensive s_nop in front of every third one (11 per step, ~10 % of a lone
-    // wave's issue slots).  Inside the block the order itself keeps every hazard: each operand was produced at
-    // least 3 instructions earlier (a DPP read needs 2 wait states behind its producer, a forwarded result 1).
-    float P, pu, pr, qx, qu, quu, Qxx, Qux, Quxi, t, t2;
+#define ILQR_QB0 "quad_perm:[0,0,0,0]"
+#define ILQR_QB1 "quad_perm:[1,1,1,1]"
+#define ILQR_QB2 "quad_perm:[2,2,2,2]"
+#define ILQR_QB3 "quad_perm:[3,3,3,3]"
+template <bool REFILL>
+ILQR_DEV void tile16_step_f32(const TileQ& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj, float& kff,
+                              bool& pd, RawTileQ& prev, const i32x4& srd, const TileOffsets& off, int soff) {
+    float P, pu, pr, qx, qu, quu, Qxx, Qux, Quxi, t, t2, inv, si1, si2, si3;
 #define DPPT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define DPPE " row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    // SK[i][0] and f_u[i] reach their (single-move) consumers 1, 2 and 17 as DPP broadcasts of a / c; SK[i][1..3] and
+    // l_ux[i] are broadcast into registers first -- four instructions that depend on the tile only, not on V_xx / V_x,
+    // and so issue while the previous step's tail is still in flight.
     asm volatile(
-        "v_mul_f32 %[P], %[si0], %[V]\n\t"                          //  1 A
-        "v_mul_f32 %[pu], %[bi], %[V]\n\t"                          //  2 B
+        "v_mov_b32_dpp %[si1], %[a] " ILQR_QB1 DPPT                   //  a  SK[i][1]
+        "v_mov_b32_dpp %[si2], %[a] " ILQR_QB2 DPPT                   //  b  SK[i][2]
+        "v_mov_b32_dpp %[si3], %[a] " ILQR_QB3 DPPT                   //  c  SK[i][3]
+        "v_mov_b32_dpp %[Quxi], %[c] " ILQR_QB2 DPPT                  //  d  Q_ux[i] (row form) = l_ux[i] + ...
+        "v_mul_f32_dpp %[P], %[a], %[V] " ILQR_QB0 DPPT               //  1 A   SK[i][0] * V
+        "v_mul_f32_dpp %[pu], %[c], %[V] " ILQR_QB0 DPPT              //  2 B   f_u[i] * V
         "v_mul_f32 %[pr], %[vj0], %[V]\n\t"                         //  3 R   f_u[j] * V[i][j]
         "v_fma_f32 %[qx], %[sj0], %[vx], %[vj1]\n\t"                //  4 C   Q_x = l_x + ...
         "v_fmac_f32_dpp %[P], %[V], %[si1] row_ror:12" DPPT           //  5 A
         "v_add_f32_dpp %[t], %[pu], %[pu] row_ror:8" DPPT             //  6 B   pu[i] + pu[i+2]
-        "v_add_f32_dpp %[t2], %[pr], %[pr] quad_perm:[1,0,3,2]" DPPT  //  7 R
-        "v_fmac_f32_dpp %[qx], %[vx], %[sj1] quad_perm:[1,2,3,0]" DPPT  //  8 C
+        "v_add_f32_dpp %[t2], %[pr], %[pr] " ILQR_QSW DPPE            //  7 R
+        : [P] "=&v"(P), [pu] "=&v"(pu), [pr] "=&v"(pr), [qx] "=&v"(qx), [t] "=&v"(t), [t2] "=&v"(t2), [si1] "=&v"(si1),
+          [si2] "=&v"(si2), [si3] "=&v"(si3), [Quxi] "=&v"(Quxi)
+        : [V] "v"(V), [vx] "v"(vx), [a] "v"(c.a), [c] "v"(c.c), [sj0] "v"(c.skj[0]), [vj0] "v"(c.vj[0]), [vj1] "v"(c.vj[1]));
+    if constexpr (REFILL) prev.template issue_part<0>(srd, off, soff);
+    asm volatile(
+        "v_fmac_f32_dpp %[qx], %[vx], %[sj1] " ILQR_QP1 DPPT          //  8 C
         "v_fmac_f32_dpp %[P], %[V], %[si2] row_ror:8" DPPT            //  9 A
-        "v_mul_f32 %[qu], %[vj0], %[vx]\n\t"                        // 10 C2  f_u[j] * V_x[j]
-        "v_add_f32_dpp %[pu], %[t], %[t] row_ror:12" DPPT             // 11 B   pu done (down the rows; column form)
-        "v_add_f32_dpp %[pr], %[t2], %[t2] quad_perm:[2,3,0,1]" DPPT  // 12 R   pr done (along the row; row form)
-        "v_fmac_f32_dpp %[qx], %[vx], %[sj2] quad_perm:[2,3,0,1]" DPPT  // 13 C
-        "v_fmac_f32_dpp %[P], %[V], %[si3] row_ror:4" DPPT            // 14 A   P done
-        "v_fma_f32 %[Qux], %[sj0], %[pu], %[vj2]\n\t"               // 15 B   Q_ux[j] = l_ux[j] + ...
-        "v_fma_f32 %[Quxi], %[si0], %[pr], %[luxi]\n\t"             // 16 R   Q_ux[i] = l_ux[i] + ...
-        "v_fmac_f32_dpp %[qx], %[vx], %[sj3] quad_perm:[3,0,1,2]" DPPT  // 17 C   Q_x done
-        "v_fmac_f32 %[qu], %[m0], %[vj3]\n\t"                       // 18 C2  + l_u on lane j = 0
-        "v_fma_f32 %[Qxx], %[sj0], %[P], %[lxx]\n\t"                // 19 A   Q_xx = l_xx + ...
-        "v_mul_f32 %[quu], %[pu], %[vj0]\n\t"                       // 20 B2  pu[j] * f_u[j]
-        "v_fmac_f32_dpp %[Qux], %[pu], %[sj1] quad_perm:[1,2,3,0]" DPPT  // 21 B
-        "v_fmac_f32_dpp %[Quxi], %[pr], %[si1] row_ror:12" DPPT       // 22 R
-        "v_fmac_f32_dpp %[Qxx], %[P], %[sj1] quad_perm:[1,2,3,0]" DPPT  // 23 A
-        "v_fmac_f32 %[quu], %[m1], %[vj3]\n\t"                      // 24 B2  + l_uu on lane j = 1
-        "v_add_f32_dpp %[t], %[qu], %[qu] quad_perm:[1,0,3,2]" DPPT   // 25 C2
-        "v_fmac_f32_dpp %[Qux], %[pu], %[sj2] quad_perm:[2,3,0,1]" DPPT  // 26 B
-        "v_fmac_f32_dpp %[Quxi], %[pr], %[si2] row_ror:8" DPPT        // 27 R
-        "v_fmac_f32_dpp %[Qxx], %[P], %[sj2] quad_perm:[2,3,0,1]" DPPT  // 28 A
-        "v_add_f32_dpp %[t2], %[quu], %[quu] quad_perm:[1,0,3,2]" DPPT  // 29 B2
-        "v_add_f32_dpp %[qu], %[t], %[t] quad_perm:[2,3,0,1]" DPPT    // 30 C2  Q_u done
-        "v_fmac_f32_dpp %[Qux], %[pu], %[sj3] quad_perm:[3,0,1,2]" DPPT  // 31 B   Q_ux (column form) done
-        "v_fmac_f32_dpp %[Quxi], %[pr], %[si3] row_ror:4" DPPT        // 32 R   Q_ux (row form) done
-        "v_fmac_f32_dpp %[Qxx], %[P], %[sj3] quad_perm:[3,0,1,2]" DPPT  // 33 A   Q_xx done
-        "v_add_f32_dpp %[quu], %[t2], %[t2] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"  // 34 B2 Q_uu done
-        : [P] "=&v"(P), [pu] "=&v"(pu), [pr] "=&v"(pr), [qx] "=&v"(qx), [qu] "=&v"(qu), [quu] "=&v"(quu),
-          [Qxx] "=&v"(Qxx), [Qux] "=&v"(Qux), [Quxi] "=&v"(Quxi), [t] "=&v"(t), [t2] "=&v"(t2)
-        : [V] "v"(V), [vx] "v"(vx), [si0] "v"(c.ski[0]), [si1] "v"(c.ski[1]), [si2] "v"(c.ski[2]), [si3] "v"(c.ski[3]),
-          [sj0] "v"(c.skj[0]), [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]), [sj3] "v"(c.skj[3]), [vj0] "v"(c.vj[0]),
-          [vj1] "v"(c.vj[1]), [vj2] "v"(c.vj[2]), [vj3] "v"(c.vj[3]), [lxx] "v"(c.lxx), [bi] "v"(c.bi),
-          [luxi] "v"(c.luxi), [m0] "v"(lc.m0), [m1] "v"(lc.m1));
+        "v_add_f32_dpp %[pu], %[t], %[t] row_ror:12" DPPT             // 10 B   pu done (down the rows; column form)
+        "v_add_f32_dpp %[pr], %[t2], %[t2] " ILQR_QP2 DPPT            // 11 R   pr done (along the row; row form)
+        "v_mul_f32 %[qu], %[vj0], %[vx]\n\t"                        // 12 C2  f_u[j] * V_x[j]
+        "v_fmac_f32_dpp %[qx], %[vx], %[sj2] " ILQR_QP2 DPPT          // 13 C
+        "v_fmac_f32_dpp %[P], %[V], %[si3] row_ror:4" DPPE            // 14 A   P done
+        : [qx] "+v"(qx), [P] "+v"(P), [qu] "=&v"(qu), [pu] "=&v"(pu), [pr] "=&v"(pr)
+        : [V] "v"(V), [vx] "v"(vx), [si2] "v"(si2), [si3] "v"(si3), [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]),
+          [vj0] "v"(c.vj[0]), [t] "v"(t), [t2] "v"(t2));
+    if constexpr (REFILL) prev.template issue_part<1>(srd, off, soff);
+    asm volatile(
+        "v_mul_f32 %[quu], %[pu], %[vj0]\n\t"                       // 15 Q   pu[j] * f_u[j]
+        "v_fma_f32 %[Qux], %[sj0], %[pu], %[vj2]\n\t"               // 16 B   Q_ux[j] = l_ux[j] + ...
+        "v_fmac_f32_dpp %[Quxi], %[a], %[pr] " ILQR_QB0 DPPT          // 17 R   Q_ux[i] += SK[i][0] * pr
+        "v_fmac_f32_dpp %[qx], %[vx], %[sj3] " ILQR_QP3 DPPT          // 18 C   Q_x done
+        "v_fmac_f32 %[quu], %[m1], %[vj3]\n\t"                      // 19 Q   + l_uu on lane j = 1
+        "v_fmac_f32 %[qu], %[m0], %[vj3]\n\t"                       // 20 C2  + l_u on lane j = 0
+        "v_fma_f32 %[Qxx], %[sj0], %[P], %[lxx]"                      // 21 A   Q_xx = l_xx + ...
+        : [quu] "=&v"(quu), [Qux] "=&v"(Qux), [Quxi] "+v"(Quxi), [Qxx] "=&v"(Qxx), [qx] "+v"(qx), [qu] "+v"(qu)
+        : [vx] "v"(vx), [a] "v"(c.a), [sj0] "v"(c.skj[0]), [sj3] "v"(c.skj[3]), [vj0] "v"(c.vj[0]), [vj2] "v"(c.vj[2]),
+          [vj3] "v"(c.vj[3]), [lxx] "v"(c.lxx), [m0] "v"(lc.m0), [m1] "v"(lc.m1), [pu] "v"(pu), [pr] "v"(pr), [P] "v"(P));
+    if constexpr (REFILL) prev.template issue_part<2>(srd, off, soff);
+    asm volatile(
+        "v_fmac_f32_dpp %[Qux], %[pu], %[sj1] " ILQR_QP1 DPPT         // 22 B
+        "v_add_f32_dpp %[t2], %[quu], %[quu] " ILQR_QSW DPPT          // 23 Q
+        "v_fmac_f32_dpp %[Quxi], %[pr], %[si1] row_ror:12" DPPT       // 24 R
+        "v_add_f32_dpp %[t], %[qu], %[qu] " ILQR_QSW DPPT             // 25 C2
+        "v_fmac_f32_dpp %[Qxx], %[P], %[sj1] " ILQR_QP1 DPPT          // 26 A
+        "v_add_f32_dpp %[quu], %[t2], %[t2] " ILQR_QP2 DPPT           // 27 Q   Q_uu done
+        "v_fmac_f32_dpp %[Qux], %[pu], %[sj2] " ILQR_QP2 DPPE         // 28 B
+        : [Qux] "+v"(Qux), [Quxi] "+v"(Quxi), [Qxx] "+v"(Qxx), [quu] "+v"(quu), [t] "=&v"(t), [t2] "=&v"(t2)
+        : [si1] "v"(si1), [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]), [pu] "v"(pu), [pr] "v"(pr), [P] "v"(P), [qu] "v"(qu));
+    if constexpr (REFILL) prev.template issue_part<3>(srd, off, soff);
+    asm volatile(
+        "v_fmac_f32_dpp %[Quxi], %[pr], %[si2] row_ror:8" DPPT        // 29 R
+        "v_add_f32_dpp %[qu], %[t], %[t] " ILQR_QP2 DPPT              // 30 C2  Q_u done
+        "v_rcp_f32 %[inv], %[quu]\n\t"                              // 31 Q   r ~ 1 / Q_uu
+        "v_fmac_f32_dpp %[Qxx], %[P], %[sj2] " ILQR_QP2 DPPT          // 32 A
+        "v_fmac_f32_dpp %[Qux], %[pu], %[sj3] " ILQR_QP3 DPPT         // 33 B   Q_ux (column form) done
+        "v_fma_f32 %[e], -%[quu], %[inv], 1.0\n\t"                  // 34 Q   e = 1 - Q_uu r
+        "v_fmac_f32_dpp %[Quxi], %[pr], %[si3] row_ror:4" DPPT        // 35 R   Q_ux (row form) done
+        "v_fmac_f32_dpp %[Qxx], %[P], %[sj3] " ILQR_QP3 DPPT          // 36 A   Q_xx done
+        "v_fmac_f32 %[inv], %[e], %[inv]"                             // 37 Q   r += e r (one Newton step)
+        : [Quxi] "+v"(Quxi), [Qxx] "+v"(Qxx), [Qux] "+v"(Qux), [qu] "=&v"(qu), [inv] "=&v"(inv), [e] "=&v"(t2)
+        : [si2] "v"(si2), [si3] "v"(si3), [sj2] "v"(c.skj[2]), [sj3] "v"(c.skj[3]), [pu] "v"(pu), [pr] "v"(pr),
+          [P] "v"(P), [t] "v"(t), [quu] "v"(quu));
+    if constexpr (REFILL) prev.template issue_part<4>(srd, off, soff);
 #undef DPPT
+#undef DPPE
     pd = quu > 0.0f;
-    const float inv = fast_rcp(quu);
     Kj = -(Qux * inv);
     kff = -(qu * inv);
     V = fmaf(Quxi, Kj, Qxx);
@@ -478,7 +588,13 @@ constexpr int kTile16PinLds = 84 * 1024;
 template <typename T, bool REG, int NXA>
 __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     // tiles in flight per lane: (D-1) * (loads per tile + 1 store) must stay <= 63 (the vmcnt field)
-    constexpr int D = sizeof(T) == 4 ? 10 : 7;
+    // SPREAD (the fp32 step without regularisation): the refill of a slot is issued one load at a time inside the NEXT
+    // step's arithmetic (tile16_step_f32<true>) instead of back to back behind its own step
+#ifndef ILQR_TILE16_D32
+#define ILQR_TILE16_D32 10
+#endif
+    constexpr bool SPREAD = sizeof(T) == 4 && !REG;
+    constexpr int D = SPREAD ? ILQR_TILE16_D32 : sizeof(T) == 4 ? 10 : 7;
     constexpr int R = gain_record(NXA, 1);     // 8 for n_x = 4
     const int lane = threadIdx.x & 63;
     const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
@@ -519,56 +635,120 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     lc.m1 = T(j == 1);
     lc.tr_byte = 4 * ((lane & 48) | (j << 2) | i);
 
-    auto do_step = [&](const Tile16<T>& c, int t) {
-        T Kj, kff;
-        bool pd;
-        if constexpr (sizeof(T) == 4 && !REG) tile16_step_f32(c, lc, V, vx, Kj, kff, pd);
-        else tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
-        all_pd = all_pd && pd;
-        if (DROP || storer) buf_store1(rgain, rec_off, uniform(t * rstride), (i == 0) ? Kj : kff);
-    };
-
     int t = N - 1;
-    // remainder steps first (no ring), so that the pipelined loop runs whole rings only
-    for (int r = N % D; r > 0; --r, --t) {
-        Tile16<T> c;
-        tile16_load_buf(c, rlin, off, uniform(t * tstride));
-        do_step(c, t);
-    }
-    if (t >= 0) {
-        // D tiles per lane in flight, loaded by asm and waited for with self-counted vmcnt (see RawTile)
-        constexpr int NL = RawTile<T>::NLOAD;
+    if constexpr (SPREAD) {
         const i32x4 srd = make_srd(a.lin, lin_bytes);
-        RawTile<T> ring[D];
-#pragma unroll
-        for (int u = 0; u < D; ++u) ring[u].template issue<true>(srd, off, uniform((t - u) * tstride));
-        // first ring pass: only the prologue's loads (plus this pass's own stores / refills) are in flight
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            ring[u].template wait<(D - 1) * NL>();
-            Tile16<T> c;
-            ring[u].unpack(c);
-            do_step(c, t - u);
-            const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
-            ring[u].template issue<false>(srd, off, uniform(tn * tstride));
+        // running byte offsets (one s_sub each per step): gain record of the step, tile of its refill
+        int goff = t * rstride, roff = 0;
+        auto step = [&](auto refill, const TileQ& c, RawTileQ& prev) {
+            T Kj, kff;
+            bool pd;
+#ifdef ILQR_T16_NOLOAD   // timing experiments only (wrong results): what the step costs without its refill / its store
+            tile16_step_f32<false>(c, lc, V, vx, Kj, kff, pd, prev, srd, off, uniform(roff > 0 ? roff : 0));
+#else
+            tile16_step_f32<decltype(refill)::value>(c, lc, V, vx, Kj, kff, pd, prev, srd, off,
+                                                     uniform(roff > 0 ? roff : 0));
+#endif
+            all_pd = all_pd && pd;
+#ifndef ILQR_T16_NOSTORE
+            buf_store1(rgain, rec_off, uniform(goff), (i == 0) ? Kj : kff);
+#else
+            if (a.N == 123457) buf_store1(rgain, rec_off, uniform(goff), (i == 0) ? Kj : kff);
+#endif
+            goff -= rstride;
+            roff -= tstride;
+        };
+        RawTileQ ring[D];
+        // remainder steps first (no ring), so that the pipelined loop runs whole rings only
+        for (int r = N % D; r > 0; --r, --t) {
+            TileQ c;
+            tileq_load_buf(c, rlin, off, uniform(t * tstride));
+            step(std::false_type{}, c, ring[0]);
         }
-        for (t -= D; t >= 0; t -= D) {
+        if (t >= 0) {
+            // D tiles per lane in flight, loaded by asm and waited for with self-counted vmcnt (see RawTile)
+            constexpr int NL = RawTileQ::NLOAD;
+#pragma unroll
+            for (int u = 0; u < D; ++u) ring[u].issue_first(srd, off, uniform((t - u) * tstride));
+            // Step u consumes slot u and, between its own instructions, refills slot u-1 (consumed one step earlier)
+            // with the tile D steps below that one.  Memory operations in issue order: prologue D*NL loads; first
+            // pass: step 0 = 1 store, step u >= 1 = NL loads + 1 store; later passes: every step NL loads + 1 store.
+            // "Slot u has landed" therefore allows
+            //   first pass:  u == 0: (D-1)*NL              (the younger prologue loads)
+            //                u >= 1: (D-1-u)*NL + u + (u-1)*NL = (D-2)*NL + u
+            //   afterwards:  1 + (D-2)*(NL+1)              (its refill sat in step u+1 of the previous pass: that
+            //                                               step's store, then D-2 whole steps)
+            // younger operations outstanding.
+            static_assert(1 + (D - 2) * (NL + 1) <= 63 && (D - 1) * NL <= 63, "vmcnt field");
+            roff = (t + 1 - D) * tstride;   // step u's refill is tile t-u+1-D
+            static_for<D>([&](auto uc) {
+                constexpr int u = decltype(uc)::value;
+                ring[u].template wait<(u == 0) ? (D - 1) * NL : (D - 2) * NL + u>();
+                TileQ c;
+                ring[u].unpack(c);
+                if constexpr (u == 0) step(std::false_type{}, c, ring[0]);   // (roff moves on: step 1 refills tile t-D)
+                else step(std::true_type{}, c, ring[u - 1]);
+            });
+            for (t -= D; t >= 0; t -= D) {
+                static_for<D>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value;
+                    ring[u].template wait<1 + (D - 2) * (NL + 1)>();
+                    TileQ c;
+                    ring[u].unpack(c);
+                    // slot u-1 (slot D-1 of the previous pass for u == 0) was consumed at step t-u+1; clamped to
+                    // tile 0 at the end of the sweep, surplus loads drained below
+                    step(std::true_type{}, c, ring[(u + D - 1) % D]);
+                });
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else {
+        auto do_step = [&](const Tile16<T>& c, int t) {
+            T Kj, kff;
+            bool pd;
+            tile16_step<T, REG>(c, lc, a.mu, V, vx, Kj, kff, pd);
+            all_pd = all_pd && pd;
+            if (DROP || storer) buf_store1(rgain, rec_off, uniform(t * rstride), (i == 0) ? Kj : kff);
+        };
+        // remainder steps first (no ring), so that the pipelined loop runs whole rings only
+        for (int r = N % D; r > 0; --r, --t) {
+            Tile16<T> c;
+            tile16_load_buf(c, rlin, off, uniform(t * tstride));
+            do_step(c, t);
+        }
+        if (t >= 0) {
+            // D tiles per lane in flight, loaded by asm and waited for with self-counted vmcnt (see RawTile)
+            constexpr int NL = RawTile<T>::NLOAD;
+            const i32x4 srd = make_srd(a.lin, lin_bytes);
+            RawTile<T> ring[D];
+#pragma unroll
+            for (int u = 0; u < D; ++u) ring[u].template issue<true>(srd, off, uniform((t - u) * tstride));
+            // first ring pass: only the prologue's loads (plus this pass's own stores / refills) are in flight
 #pragma unroll
             for (int u = 0; u < D; ++u) {
-                // slot u was refilled D steps ago; since then (D-1) steps issued 1 store + NL loads each
-                ring[u].template wait<(D - 1) * (NL + 1)>();
+                ring[u].template wait<(D - 1) * NL>();
                 Tile16<T> c;
                 ring[u].unpack(c);
                 do_step(c, t - u);
-                // refill the SAME registers with the tile D steps ahead (clamped to tile 0 at the end of the
-                // sweep: the body stays branch-free; the surplus loads are drained before the kernel ends).
-                // (Issuing the refill in the middle of the NEXT step instead, inside its latency-bound tail,
-                // was tried: 43.8 vs 40.6 us -- the extra asm statement splits hipcc's schedule of the tail.)
                 const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
                 ring[u].template issue<false>(srd, off, uniform(tn * tstride));
             }
+            for (t -= D; t >= 0; t -= D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    // slot u was refilled D steps ago; since then (D-1) steps issued 1 store + NL loads each
+                    ring[u].template wait<(D - 1) * (NL + 1)>();
+                    Tile16<T> c;
+                    ring[u].unpack(c);
+                    do_step(c, t - u);
+                    // refill the SAME registers with the tile D steps ahead (clamped to tile 0 at the end of the
+                    // sweep: the body stays branch-free; the surplus loads are drained before the kernel ends)
+                    const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
+                    ring[u].template issue<false>(srd, off, uniform(tn * tstride));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     cp.stop(a.probe, 0);
     if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;

@@ -9,9 +9,11 @@ from ilqr_amd import _lib, problems
 
 p = problems.ua_double_pendulum()
 N, R = 200, 40
-for dt in (np.float32, np.float64):
+DTS = [np.dtype(a).type for a in sys.argv[1].split(',')] if len(sys.argv) > 1 else (np.float32, np.float64)
+BS = [int(a) for a in sys.argv[2].split(',')] if len(sys.argv) > 2 else (64, 256, 512, 1024, 2048, 4096, 8192)
+for dt in DTS:
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], dt)
-    for B in (64, 256, 512, 1024, 2048, 4096, 8192):
+    for B in BS:
         x0, U0 = problems.ua_batch(B, seed=0)
         h = sysm.make_handle(horizon=N, batch=B, n_alpha=10, maxiter=1 << 30, flags=_lib.FLAG_KEEP_ITERATING)
         h.set_problem(x0, U0); h.initial_rollout(); h.iterate(2); h.linearize()
