@@ -42,7 +42,39 @@ for dt in ("f32", "f64"):
                                 "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
     json.dump(out, open(os.path.join(dst, f"pmc_traffic_{dt}.json"), "w"), indent=1)
     print(dt, {k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out["kernels"].items()}, "MB per launch")
-for dt in ("f32", "f64"):
+# the c5 shard (n=16, m=8, N=500, B=128) and the c4 MPC shard (1024 instances): stats + traffic of every kernel seen
+for w, what in (("c5", "tools/pmc_target_c5.py (c5 shard: n=16 m=8 N=500 B=128 f32, 4 iterations)"),
+                ("mpc", "tools/pmc_target_mpc.py (c4 shard: 1024 MPC instances, N=200, 2 cold + 6 warm steps, f32)")):
+    for f in newest(f"{src}/trace_{w}/*/*_kernel_stats.csv"):
+        shutil.copy(f, os.path.join(dst, f"rocprofv3_kernel_stats_{w}.csv"))
+    fetch = newest(f"{src}/pmc_fetch_{w}/*/*_counter_collection.csv")
+    write = newest(f"{src}/pmc_write_{w}/*/*_counter_collection.csv")
+    if not (fetch and write):
+        continue
+    shutil.copy(fetch[0], os.path.join(dst, f"rocprofv3_pmc_FETCH_SIZE_{w}.csv"))
+    shutil.copy(write[0], os.path.join(dst, f"rocprofv3_pmc_WRITE_SIZE_{w}.csv"))
+    per = {}
+    for path, key in ((fetch[0], "fetch"), (write[0], "write")):
+        for r in csv.DictReader(open(path)):
+            k = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ilqr::", "")
+            per.setdefault(k, {"fetch": [], "write": []})[key].append(float(r["Counter_Value"]))
+    out = {"note": f"rocprofv3 --pmc passes (separate runs, --kernel-trace only) of {what}. FETCH_SIZE/WRITE_SIZE are in "
+                   "KiB; read bytes = 2 * FETCH_SIZE * 1024 (gfx950 correction of MI355X_MICROARCH.md, HBM section).",
+           "kernels": {}}
+    for k, d in sorted(per.items()):
+        f = sum(d["fetch"]) / max(1, len(d["fetch"]))
+        wv = sum(d["write"]) / max(1, len(d["write"]))
+        out["kernels"][k] = {"FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": wv, "launches": len(d["fetch"]),
+                             "hbm_bytes_per_launch": 2 * f * 1024 + wv * 1024}
+    json.dump(out, open(os.path.join(dst, f"pmc_traffic_{w}.json"), "w"), indent=1)
+    print(w, {k: round(v["hbm_bytes_per_launch"] / 1e6, 2) for k, v in out["kernels"].items()}, "MB per launch")
+for name in ("sq_c3/summary.txt", "sq_c5/summary.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, "sq_counters_" + name.split("/")[0][3:] + ".txt"))
+for name in ("hbm_peak.json", "issue_rate.log", "range_probe.log", "f32_error.log", "c5_sweep.log", "sweep_scaling.log"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+for dt in ("f32", "f64", "c5", "mpc"):
     p = os.path.join(dst, f"rocprofv3_kernel_stats_{dt}.csv")
     if os.path.exists(p):
         print(dt, [(r["Name"][:48], r["Calls"], round(float(r["AverageNs"]) / 1e3, 1)) for r in csv.DictReader(open(p))
