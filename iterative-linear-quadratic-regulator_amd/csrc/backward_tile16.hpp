@@ -116,6 +116,25 @@ ILQR_DEV void buf_store1(__amdgpu_buffer_rsrc_t r, int voff, int soff, double v)
     __builtin_amdgcn_raw_buffer_store_b64(w, r, voff, soff, 0);
 }
 
+// a C-vector of T in 16-, 8- or 4-byte pieces (vec_pieces(C * sizeof(T)) stores)
+template <typename T, int C> ILQR_DEV void buf_store_vec(__amdgpu_buffer_rsrc_t r, int voff, int soff, const T* v) {
+    constexpr int BYTES = C * (int)sizeof(T), PB = BYTES % 16 == 0 ? 16 : BYTES % 8 == 0 ? 8 : 4, NP = BYTES / PB;
+    unsigned w[BYTES / 4];
+    __builtin_memcpy(w, v, BYTES);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        if constexpr (PB == 16) {
+            const u32x4 q = {w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + 16 * k, soff, 0);
+        } else if constexpr (PB == 8) {
+            const u32x2 q = {w[2 * k], w[2 * k + 1]};
+            __builtin_amdgcn_raw_buffer_store_b64(q, r, voff + 8 * k, soff, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(w[k], r, voff + 4 * k, soff, 0);
+        }
+    }
+}
+
 // per-lane byte offsets into this trajectory's tile, fixed for the whole sweep
 struct TileOffsets { int vi, vj, vl; };
 

@@ -1,15 +1,19 @@
 // kernels.hpp -- HIP kernels of the batched iLQR hot path (gfx950 / CDNA4).
 //
-// HBM data layout ("batch innermost", scalar type T):
-//   X    [n_slots][N+1][n_x][B]      U    [n_slots][N][n_u][B]
+// HBM data layout (scalar type T):
+//   X    [n_slots][N+1][B][n_x]      U    [n_slots][N][B][n_u]     one state / control VECTOR per (t, b): a lane reads or
+//                    writes it with one 16-byte access (n_x = 4, f32) where the batch-innermost form needed n_x
+//                    4-byte ones -- a vector-memory instruction costs a lone wave ~13 cycles of issue whatever its
+//                    width (tools/micro/issue_rate.hip), and every store sits in the same in-order vmcnt queue as
+//                    the rollout's prefetched loads
 //   gains [N][B][R]  one record per (t, b): K_t (n_u*n_x, row-major) then k_t (n_u) = U_ff of the
 //                    reference, R = n_u*n_x + n_u rounded up to a multiple of 4 scalars (16-B loads)
 //   lin  generic:    [N][E][B]   E = 2n^2+2nm+n+m+m^2, per step f_x f_u l_x l_u l_xx l_ux l_uu
 //        n=4, m=1:   [N][B][48]  one 192-B (f32) tile per (t, b), packed for the 16-lane sweep below
 //   term [n + n^2][B]                (l_f_x, l_f_xx)
 //   costs [n_alpha][B]   cost, cost_prev, alpha_taken [B]   status, iters, accepted, cur_slot [B]
-// A trajectory b is a column of every tensor, so 64 consecutive trajectories are one
-// 256-B (f32) / 512-B (f64) coalesced row per wave-instruction in every kernel.
+// 64 consecutive trajectories are one contiguous 64 * n_x * sizeof(T) block per wave-instruction in X / U and one
+// 256-B (f32) / 512-B (f64) row in the per-trajectory vectors (x0, costs, status ...).
 //
 // "Slots": the current trajectory of b lives in slot cur_slot[b]; candidate a of a
 // line-search pass is rolled out into slot (cur_slot[b] + 1 + a) % n_slots, and accepting
@@ -58,6 +62,50 @@ template <typename T> struct KArgs {
 constexpr int gain_record(int nx, int nu) { return ((nu * nx + nu) + 3) / 4 * 4; }
 
 ILQR_DEV bool traj_active(int status) { return (status & 0xff) == ILQR_TRAJ_ACTIVE; }
+
+// element offset of vector (slot, t, b) in X (Tn = N + 1, C = n_x) or U (Tn = N, C = n_u)
+ILQR_DEV size_t vec_at(size_t B, int Tn, int C, int slot, int t, size_t b) {
+    return ((((size_t)slot * Tn + t) * B) + b) * C;
+}
+// a C-vector of T at p (aligned to the largest power of two dividing C * sizeof(T), at most 16): 16-, 8- or 4-byte pieces
+typedef unsigned int vec_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int vec_u2 __attribute__((ext_vector_type(2)));
+constexpr int vec_piece(int bytes) { return bytes % 16 == 0 ? 16 : bytes % 8 == 0 ? 8 : 4; }
+constexpr int vec_pieces(int bytes) { return bytes / vec_piece(bytes); }
+template <typename T, int C> ILQR_DEV void vec_load(const T* __restrict__ p, T* o) {
+    constexpr int BYTES = C * (int)sizeof(T), PB = vec_piece(BYTES), NP = BYTES / PB;
+    if constexpr (PB == 16) {
+        vec_u4 v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = reinterpret_cast<const vec_u4*>(p)[k];
+        __builtin_memcpy(o, v, BYTES);
+    } else if constexpr (PB == 8) {
+        vec_u2 v[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) v[k] = reinterpret_cast<const vec_u2*>(p)[k];
+        __builtin_memcpy(o, v, BYTES);
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) o[i] = p[i];
+    }
+}
+template <typename T, int C> ILQR_DEV void vec_store(T* __restrict__ p, const T* v) {
+    constexpr int BYTES = C * (int)sizeof(T), PB = vec_piece(BYTES), NP = BYTES / PB;
+    if constexpr (PB == 16) {
+        vec_u4 w[NP];
+        __builtin_memcpy(w, v, BYTES);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) reinterpret_cast<vec_u4*>(p)[k] = w[k];
+    } else if constexpr (PB == 8) {
+        vec_u2 w[NP];
+        __builtin_memcpy(w, v, BYTES);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) reinterpret_cast<vec_u2*>(p)[k] = w[k];
+    } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) p[i] = v[i];
+    }
+}
 
 // Clock probe (diagnostic only; the values go to a buffer nothing else reads): one pair of stamps around
 // a whole kernel body for lane 0 of workgroup 0 gives cycles per step and the clock the chip holds.
@@ -124,34 +172,22 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
     const bool move = live && slot != 0;
     const int tt = live ? t : 0;
     const int bb = live ? b : 0;
-    const T* Xp = a.X + (((size_t)slot * (a.N + 1) + tt) * NX) * B + bb;
     if (live) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = Xp[(size_t)i * B];
+        vec_load<T, NX>(a.X + vec_at(B, a.N + 1, NX, slot, tt, bb), x);
     } else {
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = T(0);
     }
-    if (move) {
-        T* X0 = a.X + ((size_t)tt * NX) * B + bb;
-#pragma unroll
-        for (int i = 0; i < NX; ++i) X0[(size_t)i * B] = x[i];
-    }
+    if (move) vec_store<T, NX>(a.X + vec_at(B, a.N + 1, NX, 0, tt, bb), x);
     const bool has_u = inr && t < a.N;
     const int tu = has_u ? t : 0;
-    const T* Up = a.U + (((size_t)slot * a.N + tu) * NU) * B + bb;
     if (has_u && live) {
-#pragma unroll
-        for (int i = 0; i < NU; ++i) u[i] = Up[(size_t)i * B];
+        vec_load<T, NU>(a.U + vec_at(B, a.N, NU, slot, tu, bb), u);
     } else {
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = T(0);
     }
-    if (has_u && move) {
-        T* U0 = a.U + ((size_t)tu * NU) * B + bb;
-#pragma unroll
-        for (int i = 0; i < NU; ++i) U0[(size_t)i * B] = u[i];
-    }
+    if (has_u && move) vec_store<T, NU>(a.U + vec_at(B, a.N, NU, 0, tu, bb), u);
     if constexpr (!TILE16) {
         if (!live) return;
     }
@@ -584,30 +620,28 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
     ClockProbe cp;
     cp.start();
     T cost = T(0);
-    const T* Xo = a.X + ((size_t)slot * (N + 1) * NX) * B + b;
-    const T* Uo = a.U + ((size_t)slot * N * NU) * B + b;
+    // (slot, 0, b); one time step further is B * NX (B * NU) scalars on
+    const T* Xo = a.X + vec_at(B, N + 1, NX, slot, 0, b);
+    const T* Uo = a.U + vec_at(B, N, NU, slot, 0, b);
     const T* G = a.gains + (size_t)b * R;
-    T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + b;
-    T* Uc = a.U + ((size_t)cslot * N * NU) * B + b;
+    T* Xc = a.X + vec_at(B, N + 1, NX, cslot, 0, b);
+    T* Uc = a.U + vec_at(B, N, NU, cslot, 0, b);
+    const size_t sX = B * NX, sU = B * NU;
     // The per-step inputs (x_old, u_old, K, k) do not depend on the carried state, so step t+1's are
     // requested before step t's arithmetic starts: their latency hides under one RK4 step.
     // (for big gain records, n_x > 4, the double buffer would not fit the register file: load in place)
     constexpr bool PREFETCH = (R <= 32);
     constexpr int RN = PREFETCH ? R : 1, NXN = PREFETCH ? NX : 1, NUN = PREFETCH ? NU : 1;
     T xo[NX], uo[NU], g[R], xo_n[NXN], uo_n[NUN], g_n[RN];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xo[i] = Xo[(size_t)i * B];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) uo[j] = Uo[(size_t)j * B];
+    vec_load<T, NX>(Xo, xo);
+    vec_load<T, NU>(Uo, uo);
 #pragma unroll
     for (int r = 0; r < R; ++r) g[r] = G[r];
     for (int t = 0; t < N; ++t) {
         const int tn = (t + 1 < N) ? t + 1 : t;
         if constexpr (PREFETCH) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xo_n[i] = Xo[((size_t)tn * NX + i) * B];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) uo_n[j] = Uo[((size_t)tn * NU + j) * B];
+            vec_load<T, NX>(Xo + tn * sX, xo_n);
+            vec_load<T, NU>(Uo + tn * sU, uo_n);
 #pragma unroll
             for (int r = 0; r < R; ++r) g_n[r] = G[(size_t)tn * B * R + r];
         }
@@ -622,10 +656,8 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
             // u = u_old + alpha * k + K (x - x_old)   (iLQR_class.py:181-182)
             u[j] = uo[j] + alpha * g[NU * NX + j] + fb;
         }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Xc[((size_t)t * NX + i) * B] = x[i];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) Uc[((size_t)t * NU + j) * B] = u[j];
+        vec_store<T, NX>(Xc + t * sX, x);
+        vec_store<T, NU>(Uc + t * sU, u);
         cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
         T xn[NX];
         Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);  // integrator folded at compile time
@@ -639,16 +671,13 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) g[r] = g_n[r];
         } else {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) xo[i] = Xo[((size_t)tn * NX + i) * B];
-#pragma unroll
-            for (int j = 0; j < NU; ++j) uo[j] = Uo[((size_t)tn * NU + j) * B];
+            vec_load<T, NX>(Xo + tn * sX, xo);
+            vec_load<T, NU>(Uo + tn * sU, uo);
 #pragma unroll
             for (int r = 0; r < R; ++r) g[r] = G[(size_t)tn * B * R + r];
         }
     }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
+    vec_store<T, NX>(Xc + N * sX, x);
     cost += Cost<T, Dyn>::terminal(p, x);
     a.costs[(size_t)ai * B + b] = cost;
     cp.stop(a.probe, 1);
@@ -668,11 +697,15 @@ template <typename T, typename Dyn, int INTEG>
 __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     using In = FwdIn<T, NX, NU>;
-    constexpr int R = In::R, NLD = In::NLD, NST = NX + NU;
-    // ring depth: (PF-1)*(NLD+NST) <= 63 (the vmcnt field), at most 6, and at most ~130 VGPRs of ring so the
-    // rollout arithmetic still fits the 256 without spilling (see csrc/check_ring_kernels.py)
+    // stores per step: the pieces of the state and of the control vector (one 16-byte store for n_x = 4 in fp32)
+    constexpr int R = In::R, NLD = In::NLD, NST = vec_pieces(NX * (int)sizeof(T)) + vec_pieces(NU * (int)sizeof(T));
+    // ring depth: (PF-1)*(NLD+NST) <= 63 (the vmcnt field), at most ILQR_RING_PF_MAX, and at most ~130 VGPRs of ring so
+    // the rollout arithmetic still fits the 256 without spilling (see csrc/check_ring_kernels.py)
+#ifndef ILQR_RING_PF_MAX
+#define ILQR_RING_PF_MAX 6
+#endif
     constexpr int SLOT_REGS = (NX + NU + R) * (int)sizeof(T) / 4;
-    constexpr int PF_CNT = (63 / (NLD + NST)) + 1 > 6 ? 6 : (63 / (NLD + NST)) + 1;
+    constexpr int PF_CNT = (63 / (NLD + NST)) + 1 > ILQR_RING_PF_MAX ? ILQR_RING_PF_MAX : (63 / (NLD + NST)) + 1;
     // (the fp64 backward-Euler step -- Newton loop with an LU solve -- needs more registers of its own: one slot fewer)
     constexpr int RING_CAP = (sizeof(T) == 8 && INTEG == ILQR_INT_BACKWARD_EULER) ? 104 : 130;
     constexpr int PF = PF_CNT * SLOT_REGS > RING_CAP ? RING_CAP / SLOT_REGS : PF_CNT;
@@ -704,8 +737,7 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     ClockProbe cp;
     cp.start();
     T cost = T(0);
-    T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + bb;
-    const int rowB = (int)(B * sizeof(T));
+    const int stepX = (int)(B * NX * sizeof(T)), stepU = (int)(B * NU * sizeof(T)), stepG = (int)(B * R * sizeof(T));
     const unsigned bytesX = (unsigned)((size_t)a.n_slots * (N + 1) * NX * B * sizeof(T));
     const unsigned bytesU = (unsigned)((size_t)a.n_slots * N * NU * B * sizeof(T));
     // candidate stores go through buffer descriptors: the time step moves in the scalar offset (no per-store
@@ -717,36 +749,35 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     // so fp64 keeps the exec-mask predicate)
     constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
     const int kDropped = 0x7ffffff0;
-    const int vXc = (live || !DROP) ? (int)(((size_t)cslot * (N + 1) * NX * B + bb) * sizeof(T)) : kDropped;
-    const int vUc = (live || !DROP) ? (int)(((size_t)cslot * N * NU * B + bb) * sizeof(T)) : kDropped;
+    const int vXc = (live || !DROP) ? (int)(vec_at(B, N + 1, NX, cslot, 0, bb) * sizeof(T)) : kDropped;
+    const int vUc = (live || !DROP) ? (int)(vec_at(B, N, NU, cslot, 0, bb) * sizeof(T)) : kDropped;
     const __amdgpu_buffer_rsrc_t srdG = make_rsrc(a.gains, (unsigned)((size_t)N * B * R * sizeof(T)));
-    const int vx = (int)(((size_t)slot * (N + 1) * NX * B + bb) * sizeof(T));
-    const int vu = (int)(((size_t)slot * N * NU * B + bb) * sizeof(T));
+    const int vx = (int)(vec_at(B, N + 1, NX, slot, 0, bb) * sizeof(T));
+    const int vu = (int)(vec_at(B, N, NU, slot, 0, bb) * sizeof(T));
     const int vg = (int)((size_t)bb * R * sizeof(T));
     // first: the slot holds nothing yet (prologue); otherwise a refill, tied to the slot's consumed inputs
     auto issue = [&](In& in, int t, auto first) {
-        in.template issue<decltype(first)::value>(rXc, rUc, srdG, vx, vu, vg, t * NX * rowB, t * NU * rowB, t * R * rowB, rowB);
+        in.template issue<decltype(first)::value>(rXc, rUc, srdG, vx, vu, vg, t * stepX, t * stepU, t * stepG);
     };
     constexpr std::true_type kFirst{};
     constexpr std::false_type kRefill{};
     auto do_step = [&](const In& in, int t) {
-        T dx[NX];
+        T xo[NX], uo[NU], dx[NX];
+        in.unpack(xo, uo);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) dx[i] = x[i] - in.xo[i];
+        for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
             T fb = T(0);
 #pragma unroll
             for (int i = 0; i < NX; ++i) fb += in.gain(j * NX + i) * dx[i];
-            u[j] = in.uo[j] + alpha * in.gain(NU * NX + j) + fb;   // iLQR_class.py:181-182
+            u[j] = uo[j] + alpha * in.gain(NU * NX + j) + fb;   // iLQR_class.py:181-182
         }
-        // exactly NX + NU stores per step for every wave that is still running (they are counted)
-#pragma unroll
-        for (int i = 0; i < NX; ++i)
-            if (DROP || live) buf_store1(rXc, vXc, uniform((t * NX + i) * rowB), x[i]);
-#pragma unroll
-        for (int j = 0; j < NU; ++j)
-            if (DROP || live) buf_store1(rUc, vUc, uniform((t * NU + j) * rowB), u[j]);
+        // exactly NST stores per step for every wave that is still running (they are counted)
+        if (DROP || live) {
+            buf_store_vec<T, NX>(rXc, vXc, uniform(t * stepX), x);
+            buf_store_vec<T, NU>(rUc, vUc, uniform(t * stepU), u);
+        }
         cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
         T xn[NX];
         Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);
@@ -782,8 +813,7 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (live) {
-#pragma unroll
-        for (int i = 0; i < NX; ++i) Xc[((size_t)N * NX + i) * B] = x[i];
+        vec_store<T, NX>(a.X + vec_at(B, N + 1, NX, cslot, N, bb), x);
         cost += Cost<T, Dyn>::terminal(p, x);
         a.costs[(size_t)ai * B + b] = cost;
     }
@@ -1008,12 +1038,12 @@ __global__ void __launch_bounds__(64) mpc_advance_kernel(MpcArgs<T> a) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
     const size_t B = a.B;
-    T* Uc = a.U + ((size_t)a.cur_slot[b] * a.N * NU) * B + b;
+    T* Uc = a.U + vec_at(B, a.N, NU, a.cur_slot[b], 0, b);
+    const size_t sU = B * NU;
     T x[NX], u[NU], xn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = a.plant_x[(size_t)i * B + b];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) u[j] = Uc[(size_t)j * B];
+    vec_load<T, NU>(Uc, u);
     Stepper<T, Dyn>::step(a.plant_integ, a.params, a.dt, x, u, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1025,35 +1055,37 @@ __global__ void __launch_bounds__(64) mpc_advance_kernel(MpcArgs<T> a) {
     for (int j = 0; j < NU; ++j)
         if (a.u_log) a.u_log[((size_t)a.step * B + b) * NU + j] = u[j];
     if (a.cost_log) a.cost_log[(size_t)a.step * B + b] = a.cost[b];
-    for (int t = 0; t + 1 < a.N; ++t)
-#pragma unroll
-        for (int j = 0; j < NU; ++j) Uc[((size_t)t * NU + j) * B] = Uc[((size_t)(t + 1) * NU + j) * B];
+    for (int t = 0; t + 1 < a.N; ++t) {
+        T un[NU];
+        vec_load<T, NU>(Uc + (t + 1) * sU, un);
+        vec_store<T, NU>(Uc + t * sU, un);
+    }
 }
 
 // ---------------------------------------------------------------------------
 // layout conversion between the host layouts of the C-ABI (leading batch axis in
 // front of the reference layout) and the device's batch-innermost slots.
-// dense[b][c][t] (c = component, t = time) <-> slots[slot(b)][t][c][b]
+// dense[b][c][t] (c = component, t = time) <-> slots[slot(b)][t][b][c]
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void scatter_ct_kernel(const T* dense, T* slots, const int* cur_slot, int B, int C, int Tn) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * C * Tn) return;
-    const int b = (int)(idx % B);
-    const int c = (int)((idx / B) % C);
+    const int c = (int)(idx % C);
+    const int b = (int)((idx / C) % B);
     const int t = (int)(idx / ((size_t)B * C));
     const int s = cur_slot ? cur_slot[b] : 0;
-    slots[(((size_t)s * Tn + t) * C + c) * B + b] = dense[((size_t)b * C + c) * Tn + t];
+    slots[(((size_t)s * Tn + t) * B + b) * C + c] = dense[((size_t)b * C + c) * Tn + t];
 }
 template <typename T>
 __global__ void gather_ct_kernel(T* dense, const T* slots, const int* cur_slot, int B, int C, int Tn) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * C * Tn) return;
-    const int b = (int)(idx % B);
-    const int c = (int)((idx / B) % C);
+    const int c = (int)(idx % C);
+    const int b = (int)((idx / C) % B);
     const int t = (int)(idx / ((size_t)B * C));
     const int s = cur_slot ? cur_slot[b] : 0;
-    dense[((size_t)b * C + c) * Tn + t] = slots[(((size_t)s * Tn + t) * C + c) * B + b];
+    dense[((size_t)b * C + c) * Tn + t] = slots[(((size_t)s * Tn + t) * B + b) * C + c];
 }
 // dense[b][t][c] <-> dev[t][c][b]   (K, ILQR_LIN, x0 with Tn = 1)
 template <typename T>

@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(64) linearize_wave_kernel(KArgs<T> a) {
     const int slot = a.cur_slot[b];
     const T* __restrict__ p = a.params;
     __shared__ T dx[NX], uu[NU];
-    if (lane < NX) dx[lane] = a.X[(((size_t)slot * (a.N + 1) + t) * NX + lane) * B + b] - p[PL::XT + lane];
-    if (lane < NU && t < a.N) uu[lane] = a.U[(((size_t)slot * a.N + t) * NU + lane) * B + b];
+    if (lane < NX) dx[lane] = a.X[vec_at(B, a.N + 1, NX, slot, t, b) + lane] - p[PL::XT + lane];
+    if (lane < NU && t < a.N) uu[lane] = a.U[vec_at(B, a.N, NU, slot, t, b) + lane];
     __syncthreads();
     if (t == a.N) {
         for (int e = lane; e < NX + NX * NX; e += 64) {
@@ -141,11 +141,12 @@ __global__ void __launch_bounds__(64) forward_wave_kernel(KArgs<T> a) {
     __shared__ T sx[NX], su[NU];
     if (lane < NX) sx[lane] = a.x0[(size_t)lane * B + b];
     __syncthreads();
-    const T* Xo = a.X + ((size_t)slot * (N + 1) * NX) * B + b;
-    const T* Uo = a.U + ((size_t)slot * N * NU) * B + b;
+    const T* Xo = a.X + vec_at(B, N + 1, NX, slot, 0, b);
+    const T* Uo = a.U + vec_at(B, N, NU, slot, 0, b);
     const T* G = a.gains + (size_t)b * R;
-    T* Xc = a.X + ((size_t)cslot * (N + 1) * NX) * B + b;
-    T* Uc = a.U + ((size_t)cslot * N * NU) * B + b;
+    T* Xc = a.X + vec_at(B, N + 1, NX, cslot, 0, b);
+    T* Uc = a.U + vec_at(B, N, NU, cslot, 0, b);
+    const size_t sX = B * NX, sU = B * NU;   // one time step further
     T cx = T(0), cu = T(0);
     for (int t = 0; t < N; ++t) {
         // ---- u = u_old + alpha k + K (x - x_old)   (iLQR_class.py:181-182) -------------------------
@@ -153,14 +154,14 @@ __global__ void __launch_bounds__(64) forward_wave_kernel(KArgs<T> a) {
 #pragma unroll
         for (int e = 0; e < CK; ++e) {
             const int c = pk * CK + e;
-            if (c < NX) part += G[(size_t)t * B * R + j * NX + c] * (sx[c] - Xo[((size_t)t * NX + c) * B]);
+            if (c < NX) part += G[(size_t)t * B * R + j * NX + c] * (sx[c] - Xo[t * sX + c]);
         }
 #pragma unroll
         for (int m = 1; m < PK; m <<= 1) part += shfl_xor_t(part, m);
-        const T uj = Uo[((size_t)t * NU + j) * B] + alpha * G[(size_t)t * B * R + NU * NX + j] + part;
+        const T uj = Uo[t * sU + j] + alpha * G[(size_t)t * B * R + NU * NX + j] + part;
         if (pk == 0) {
             su[j] = uj;
-            Uc[((size_t)t * NU + j) * B] = uj;
+            Uc[t * sU + j] = uj;
         }
         __syncthreads();
         // ---- x+ = A x + B u ; stage cost partials ----------------------------------------------------
@@ -181,7 +182,7 @@ __global__ void __launch_bounds__(64) forward_wave_kernel(KArgs<T> a) {
         if (lane < NU * NU) cu += Rco * su[jr] * su[cr];
 #pragma unroll
         for (int m = 1; m < PR; m <<= 1) acc += shfl_xor_t(acc, m);
-        if (pa == 0) Xc[((size_t)t * NX + i) * B] = xi;   // the state USED at this step (:188)
+        if (pa == 0) Xc[t * sX + i] = xi;   // the state USED at this step (:188)
         __syncthreads();
         if (pa == 0) sx[i] = acc;
         __syncthreads();
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(64) forward_wave_kernel(KArgs<T> a) {
 #pragma unroll
     for (int q = 0; q < CA; ++q) qf += Qfco[q] * (sx[pa * CA + q] - xtq[q]);
     const T xi = sx[i];
-    if (pa == 0) Xc[((size_t)N * NX + i) * B] = xi;
+    if (pa == 0) Xc[N * sX + i] = xi;
     T total = (T(0.5) * cx + T(0.5) * cu) * a.dt + T(0.5) * (xi - xti) * qf;
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) total += shfl_xor_t(total, m);

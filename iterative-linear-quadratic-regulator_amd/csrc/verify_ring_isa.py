@@ -47,9 +47,10 @@ _OPSEL = re.compile(r"\bop_sel:\[([01,]+)\]")
 _OPSELHI = re.compile(r"\bop_sel_hi:\[([01,]+)\]")
 
 
-def _pk_touch(ops):
+def _pk_touch(ops, mov=False):
     """Registers a packed-math instruction really accesses: a 64-bit SOURCE operand whose op_sel / op_sel_hi bits
-    both select the same half reads only that register (hipcc broadcasts a scalar over both lanes this way)."""
+    both select the same half reads only that register (hipcc broadcasts a scalar over both lanes this way).
+    v_pk_mov_b32 (mov=True) reads ONE half of each source: D.lo = src0[op_sel[0]], D.hi = src1[op_sel[1]]."""
     body = ops.split(" op_sel")[0]
     fields = [f.strip() for f in body.split(",")]
     sel = [int(c) for c in _OPSEL.search(ops).group(1).split(",")] if _OPSEL.search(ops) else []
@@ -59,7 +60,7 @@ def _pk_touch(ops):
         r = sorted(_regs(f))
         if len(r) == 2:
             lo_sel = sel[k] if k < len(sel) else 0
-            hi_sel = hi[k] if k < len(hi) else 1
+            hi_sel = lo_sel if mov else (hi[k] if k < len(hi) else 1)
             if lo_sel == hi_sel:
                 r = [r[lo_sel]]
         out.update(r)
@@ -77,7 +78,7 @@ class Inst:
         self.touch = frozenset(_regs(ops))
         m = self.mnem
         if m.startswith("v_pk_"):
-            self.touch = frozenset(_pk_touch(ops))
+            self.touch = frozenset(_pk_touch(ops, mov=(m == "v_pk_mov_b32")))
         if m.startswith(_VMEM_LOAD):
             self.kind = "load"
             if " lds" in ops or m.startswith("global_load_lds"):

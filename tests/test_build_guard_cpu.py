@@ -143,6 +143,11 @@ def test_isa_verifier_follows_loops_and_both_sides_of_branches():
 """
     assert _verdict(pk) == []
     assert _verdict(pk.replace("op_sel_hi:[0,1,1]", "op_sel_hi:[1,1,1]")) != []
+    # v_pk_mov_b32 reads one half of each source: D.lo = src0[op_sel[0]], D.hi = src1[op_sel[1]]
+    mov = pk.replace("v_pk_fma_f32 v[30:31], v[20:21], v[32:33], v[34:35] op_sel_hi:[0,1,1]",
+                     "v_pk_mov_b32 v[30:31], v[32:33], v[20:21] op_sel:[1,0]")
+    assert _verdict(mov) == []                                   # reads v33 and v20; v21 is the load in flight
+    assert _verdict(mov.replace("op_sel:[1,0]", "op_sel:[1,1]")) != []
 
 
 @pytest.mark.parametrize("log", ["ilqr_f32.isa.log", "ilqr_f64.isa.log"])
