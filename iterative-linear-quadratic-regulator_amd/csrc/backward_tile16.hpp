@@ -678,6 +678,10 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
             roff -= tstride;
         };
         RawTileQ ring[D];
+#ifdef ILQR_T16_STAMPS
+        long long stamp_cal = 0, stamp_wait = 0;
+        const long long stamp_t0 = __builtin_readcyclecounter();
+#endif
         // remainder steps first (no ring), so that the pipelined loop runs whole rings only
         for (int r = N % D; r > 0; --r, --t) {
             TileQ c;
@@ -711,7 +715,16 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
             for (t -= D; t >= 0; t -= D) {
                 static_for<D>([&](auto uc) {
                     constexpr int u = decltype(uc)::value;
+#ifdef ILQR_T16_STAMPS   // diagnostic build (tools/t16_stamps.py): cycles spent in the ring's wait, and an empty pair
+                    const long long w0 = __builtin_readcyclecounter();
+                    const long long w1 = __builtin_readcyclecounter();
                     ring[u].template wait<1 + (D - 2) * (NL + 1)>();
+                    const long long w2 = __builtin_readcyclecounter();
+                    stamp_cal += w1 - w0;
+                    stamp_wait += w2 - w1;
+#else
+                    ring[u].template wait<1 + (D - 2) * (NL + 1)>();
+#endif
                     TileQ c;
                     ring[u].unpack(c);
                     // slot u-1 (slot D-1 of the previous pass for u == 0) was consumed at step t-u+1; clamped to
@@ -721,6 +734,11 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#ifdef ILQR_T16_STAMPS
+        if (a.probe && blockIdx.x == 7 && threadIdx.x == 0) {
+            a.probe[2] = stamp_wait; a.probe[3] = stamp_cal; a.probe[4] = __builtin_readcyclecounter() - stamp_t0;   // (slots no ClockProbe uses for the sweep)
+        }
+#endif
     } else {
         auto do_step = [&](const Tile16<T>& c, int t) {
             T Kj, kff;
