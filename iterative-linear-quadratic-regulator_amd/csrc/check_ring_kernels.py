@@ -20,7 +20,7 @@ usage: check_ring_kernels.py <hipcc stderr log> [<device .s>]      (exit 1 and a
 import re
 import sys
 
-GUARDED = ("forward_ring_kernel", "backward_tile16_kernel", "backward_tile16m2_kernel")
+GUARDED = ("forward_ring_kernel", "backward_tile16_kernel", "backward_tile16m2_kernel", "forward_mfma16_kernel")
 
 
 def parse(log_text):
@@ -43,8 +43,14 @@ def parse(log_text):
     return out
 
 
+# Kernels whose AGPRs are MFMA accumulators, not spill space: the AGPR count says nothing there, and a spill into an
+# AGPR (v_accvgpr_write of an in-flight register) is caught by the assembly check instead.
+MFMA_KERNELS = ("forward_mfma16_kernel",)
+
+
 def violations(kernels):
-    return [k for k in kernels if any(g in k["name"] for g in GUARDED) and (k["agprs"] or k["vspill"])]
+    return [k for k in kernels if any(g in k["name"] for g in GUARDED) and
+            ((k["agprs"] and not any(m in k["name"] for m in MFMA_KERNELS)) or k["vspill"])]
 
 
 def forward_ring_integrator(name):

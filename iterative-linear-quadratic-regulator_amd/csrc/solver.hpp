@@ -21,6 +21,7 @@
 
 #include "kernels_wave.hpp"
 #include "backward_mfma16.hpp"
+#include "forward_mfma16.hpp"
 
 namespace ilqr {
 
@@ -238,6 +239,17 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
                 else
                     ILQR_LAUNCH((forward_kernel<T, Dyn, ILQR_INT_EULER>), dim3((a.B + 63) / 64, a.n_pass), dim3(64), 0, s, a);
                 return;
+            }
+            if constexpr (NX == 16 && NU == 8) {
+                // all candidates of a trajectory as the columns of one matrix recursion on the matrix cores
+                // (forward_mfma16.hpp); 32-bit buffer offsets into X, U and the gains
+                static const bool wave = getenv("ILQR_FORWARD_WAVE") != nullptr;   // A/B: wave per (trajectory, alpha)
+                const size_t bytes_x = (size_t)a.n_slots * (a.N + 1) * NX * a.B * sizeof(T);
+                const size_t bytes_g = (size_t)a.N * a.B * gain_record(NX, NU) * sizeof(T);
+                if (!wave && a.n_pass <= 16 && std::max(bytes_x, bytes_g) < (1ull << 31)) {
+                    ILQR_LAUNCH((forward_mfma16_kernel<T>), dim3(a.B), dim3(64), 0, s, a);
+                    return;
+                }
             }
             ILQR_LAUNCH((forward_wave_kernel<T, NX, NU>), dim3(a.B, a.n_pass), dim3(64), 0, s, a);
         };

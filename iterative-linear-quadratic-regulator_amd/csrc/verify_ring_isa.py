@@ -23,7 +23,7 @@ usage: verify_ring_isa.py <device .s file> [kernel-name-substring ...]      exit
 import re
 import sys
 
-GUARDED = ("forward_ring_kernel", "backward_tile16_kernel", "backward_tile16m2_kernel")
+GUARDED = ("forward_ring_kernel", "backward_tile16_kernel", "backward_tile16m2_kernel", "forward_mfma16_kernel")
 
 _VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 _VMCNT = re.compile(r"vmcnt\((\d+)\)")
