@@ -644,7 +644,9 @@ __global__ void __launch_bounds__(256) backward_tile16_kernel(KArgs<T> a) {
     off.vl = (int)((b * kTile16 + l16) * sizeof(T));
     // lanes (0, j) store K[j], lane (1, 0) stores k.  fp32: every other lane's offset lies beyond the descriptor's
     // range, where the hardware drops the store -- no exec-mask juggling around the one counted store of a step.
-    // (The same trick on the 64-bit store of the fp64 sweep produced wrong gains; it keeps the predicate.)
+    // (Measured rule, tools/micro/range_probe.hip: the check is per dword against num_records, for 32-, 64- and 128-bit
+    // accesses alike.  The wrong fp64 gains of round 1 were not the store: hipcc had copied a ring register whose load
+    // was still in flight -- see RawTile.  fp64 keeps the exec predicate because it measured 8 % faster there.)
     constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
     const bool storer = act && ((i == 0 && j < NXA) || l16 == 4);
     const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : NXA)) * sizeof(T)) : 0x7ffffff0;

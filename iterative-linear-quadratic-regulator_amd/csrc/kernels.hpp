@@ -745,8 +745,8 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     // hardware drops the store (no exec-mask juggling around the counted stores)
     // (the same descriptors serve the ring's asm loads: one set of SGPRs)
     const __amdgpu_buffer_rsrc_t rXc = make_rsrc(a.X, bytesX), rUc = make_rsrc(a.U, bytesU);
-    // (32-bit stores only: the same trick on the 64-bit stores of the fp64 kernels wrote wrong data in the sweep,
-    // so fp64 keeps the exec-mask predicate)
+    // (fp32 only: the fp64 kernels keep the exec-mask predicate, which measured faster there; the dropped form is
+    // correct for 64-bit stores too -- backward_tile16.hpp, DROP)
     constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
     const int kDropped = 0x7ffffff0;
     const int vXc = (live || !DROP) ? (int)(vec_at(B, N + 1, NX, cslot, 0, bb) * sizeof(T)) : kDropped;
