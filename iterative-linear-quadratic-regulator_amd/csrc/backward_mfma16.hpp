@@ -122,6 +122,12 @@ ILQR_DEV void buf_store16(__amdgpu_buffer_rsrc_t r, int voff, const double* v) {
     __builtin_amdgcn_raw_buffer_store_b128(w, r, voff, 0, 0);
 }
 
+template <typename T> ILQR_DEV __amdgpu_buffer_rsrc_t tile16x8_rsrc_of(const T* rec) {
+    constexpr int NX = 16, NU = 8;
+    constexpr int E = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
+    return make_rsrc(rec, E * (int)sizeof(T));
+}
+
 template <typename T>
 ILQR_DEV void tile16x8_load(Tile16x8<T>& t, const T* rec, const Lane16x8& o) {
     using MF = Mfma16<T>;
@@ -162,7 +168,11 @@ ILQR_DEV void tile16x8_load(Tile16x8<T>& t, const T* rec, const Lane16x8& o) {
 #define ILQR_STAMP(k, v) do {} while (0)
 #endif
 
-template <typename T>
+// CONST: the matrices of the expansion (f_x, f_u, l_xx, l_ux, l_uu) do not depend on (t, b) -- a Linear system with the
+// parameter-block quadratic cost, which is what the library's own linearisation of n = 16 always is -- so they are
+// loaded once and a step fetches l_x and l_u only (2 loads instead of 22).  Caller-supplied tensors (ilqr_backward_tensors)
+// take the general form.
+template <typename T, bool CONST>
 __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
     using MF = Mfma16<T>;
     using acc = typename MF::acc;
@@ -232,7 +242,13 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
 
     for (int t = N - 1; t >= 0; --t) {
         // the next step's expansion does not depend on the carried value function: request it now
-        tile16x8_load(nxt, lin + (size_t)(t > 0 ? t - 1 : 0) * tstride, off);
+        if constexpr (CONST) {
+            const __amdgpu_buffer_rsrc_t rn = tile16x8_rsrc_of(lin + (size_t)(t > 0 ? t - 1 : 0) * tstride);
+            nxt.lx = buf_load1(rn, off.vLx, S * (NX * NX + NX * NU), T(0));
+            nxt.lu = buf_load1(rn, off.vLu, S * (NX * NX + NX * NU + NX), T(0));
+        } else {
+            tile16x8_load(nxt, lin + (size_t)(t > 0 ? t - 1 : 0) * tstride, off);
+        }
         ILQR_STAMP(8, off.vA);
         ILQR_STAMP(9, cur.Bm[0] + cur.A[3] + cur.lu + V[0]);
 
@@ -436,7 +452,8 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
             arr(d0 + d1, V);
         }
         ILQR_STAMP(6, V[0] + Vx[0]);
-        cur = nxt;
+        if constexpr (CONST) { cur.lx = nxt.lx; cur.lu = nxt.lu; }
+        else cur = nxt;
         ILQR_STAMP(7, cur.A[0]);
     }
 #ifdef ILQR_MFMA16_STAMPS

@@ -100,6 +100,7 @@ template <typename T> struct Ops {
     int tile_scalars = 0;
     bool lin_aos = false; // expansion stored as [N][B][E] records (n_x > 4, wave-cooperative kernels)
     bool canonical = false;  // linearize moves every current trajectory into slot 0 (then cur_slot is reset)
+    bool const_lin = false;  // the system's expansion has constant matrices (Linear dynamics + parameter-block cost): KArgs::const_lin
 };
 
 // linearize / forward are compiled once per integrator so the integrator switch folds away and each
@@ -223,6 +224,7 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
     using Dyn = Linear<T, NX, NU>;
     Ops<T> o;
     o.lin_aos = true;
+    o.const_lin = true;      // Linear dynamics, parameter-block quadratic cost
     o.lin_stride = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
     for (int k = 0; k < 5; ++k) {
         o.linearize[k] = [](const KArgs<T>& a, hipStream_t s) {
@@ -259,7 +261,9 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
             // the (16, 8) sweep runs on the matrix cores (backward_mfma16.hpp); mu > 0 keeps the LDS form
             static const bool lds_form = getenv("ILQR_BACKWARD_WAVE_LDS") != nullptr;   // A/B switch
             if (a.mu == T(0) && !lds_form) {
-                ILQR_LAUNCH((backward_mfma16_kernel<T>), dim3(a.B), dim3(64), 0, s, a);
+                static const bool general = getenv("ILQR_MFMA16_GENERAL") != nullptr;   // A/B switch
+                if (a.const_lin && !general) ILQR_LAUNCH((backward_mfma16_kernel<T, true>), dim3(a.B), dim3(64), 0, s, a);
+                else ILQR_LAUNCH((backward_mfma16_kernel<T, false>), dim3(a.B), dim3(64), 0, s, a);
                 return;
             }
         }
@@ -381,6 +385,7 @@ template <typename T> struct DeviceState {
     T *costs = nullptr, *cost = nullptr, *cost_prev = nullptr, *alpha_taken = nullptr;
     int *cur_slot = nullptr, *status = nullptr, *iters = nullptr, *accepted = nullptr, *counters = nullptr;
     bool slots_stale = false;   // linearize has moved the active trajectories to slot 0, cur_slot not yet reset
+    bool lin_const = false;     // `lin` holds the library's own linearisation of a system whose matrices are constant (KArgs::const_lin)
 };
 
 template <typename T> class SolverT : public SolverBase {
@@ -738,6 +743,7 @@ template <typename T> class SolverT : public SolverBase {
         ops.linearize[cfg.integrator](a, stream);
         timer.end(stream);
         s.slots_stale = ops.canonical;   // the sweep that follows resets cur_slot (KArgs::reset_slots)
+        s.lin_const = ops.const_lin;
         return check_launch();
     }
     // cur_slot must be truthful before anything but the backward sweep looks at it
@@ -751,6 +757,7 @@ template <typename T> class SolverT : public SolverBase {
     int do_backward(DeviceState<T>& s) {
         KArgs<T> a = kargs(s);
         a.reset_slots = s.slots_stale ? 1 : 0;
+        a.const_lin = s.lin_const ? 1 : 0;
         timer.begin(ILQR_PHASE_BACKWARD, stream);
         ops.backward(a, stream);
         timer.end(stream);
@@ -976,6 +983,7 @@ template <typename T> class SolverT : public SolverBase {
         int rc;
         if ((rc = ensure_fn()) || (rc = reset_fn())) return rc;
         if ((rc = up_lin(lin, fn.lin))) return rc;
+        fn.lin_const = false;    // caller-supplied tensors: anything goes
         if (ops.tile16 && NX < 4) {
             // the sweep reads [V_x (4) | V_xx (4 x 4)] zero-padded
             std::vector<T> pad((size_t)B * 20, T(0));
