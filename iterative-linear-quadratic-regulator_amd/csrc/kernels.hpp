@@ -57,6 +57,7 @@ template <typename T> struct KArgs {
     int reset_slots;   // backward kernels: set cur_slot[b] = 0 for active b (after a canonicalising linearize)
     int const_lin;     // the expansion's matrices are the same at every (t, b) (a Linear system with the built-in quadratic
                        // cost: only l_x, l_u vary); set by the host for the library's own linearisation, never for caller tensors
+    int lin_sparse;    // linearize_wave_kernel: write the constant matrices at t = N-1 only (what the CONST sweep reads), l_x, l_u everywhere
     const T* params;
     long long* probe;  // diagnostic: {shader cycles, 100 MHz ticks} of block 0 per kernel, or nullptr
 };

@@ -55,7 +55,12 @@ __global__ void __launch_bounds__(64) linearize_wave_kernel(KArgs<T> a) {
     }
     const bool euler = a.integ != ILQR_INT_DISCRETE;
     T* out = a.lin + ((size_t)t * B + b) * E;
+    // The matrices of a Linear system's expansion are the same at every (t, b): when the sweep that follows is the
+    // constant-matrix form (backward_mfma16_kernel<T, true>) it reads them from the record of t = N-1 only, and writing
+    // them 500 times over was 97 % of this kernel's stores (KArgs::lin_sparse; ilqr_get(ILQR_LIN) re-runs the full form).
+    const bool gradients_only = a.lin_sparse && t != a.N - 1;
     for (int e = lane; e < E; e += 64) {
+        if (gradients_only && (e < oLX || e >= oLXX)) continue;
         T v;
         if (e < oFU) {
             const int i = e / NX, j = e % NX;

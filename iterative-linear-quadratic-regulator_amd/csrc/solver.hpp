@@ -101,6 +101,7 @@ template <typename T> struct Ops {
     bool lin_aos = false; // expansion stored as [N][B][E] records (n_x > 4, wave-cooperative kernels)
     bool canonical = false;  // linearize moves every current trajectory into slot 0 (then cur_slot is reset)
     bool const_lin = false;  // the system's expansion has constant matrices (Linear dynamics + parameter-block cost): KArgs::const_lin
+    bool (*sweep_reads_sparse)(T mu) = nullptr;   // does the backward dispatch take the constant-matrix form for this mu?
 };
 
 // linearize / forward are compiled once per integrator so the integrator switch folds away and each
@@ -256,6 +257,11 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
             ILQR_LAUNCH((forward_wave_kernel<T, NX, NU>), dim3(a.B, a.n_pass), dim3(64), 0, s, a);
         };
     }
+    if constexpr (NX == 16 && NU == 8) {
+        o.sweep_reads_sparse = [](T mu) {
+            return mu == T(0) && getenv("ILQR_BACKWARD_WAVE_LDS") == nullptr && getenv("ILQR_MFMA16_GENERAL") == nullptr;
+        };
+    }
     o.backward = [](const KArgs<T>& a, hipStream_t s) {
         if constexpr (NX == 16 && NU == 8) {
             // the (16, 8) sweep runs on the matrix cores (backward_mfma16.hpp); mu > 0 keeps the LDS form
@@ -386,6 +392,7 @@ template <typename T> struct DeviceState {
     int *cur_slot = nullptr, *status = nullptr, *iters = nullptr, *accepted = nullptr, *counters = nullptr;
     bool slots_stale = false;   // linearize has moved the active trajectories to slot 0, cur_slot not yet reset
     bool lin_const = false;     // `lin` holds the library's own linearisation of a system whose matrices are constant (KArgs::const_lin)
+    bool lin_full = true;       // every record of `lin` holds its matrices (false after a sparse linearise: see KArgs::lin_sparse)
 };
 
 template <typename T> class SolverT : public SolverBase {
@@ -725,7 +732,11 @@ template <typename T> class SolverT : public SolverBase {
             case ILQR_K: return down_gain_K(dst, st.gains);
             case ILQR_X0: return down_tc(dst, st.x0, NX, 1);
             case ILQR_PLANT_X: return down_tc(dst, plant_x, NX, 1);
-            case ILQR_LIN: return down_lin(dst, st.lin);
+            case ILQR_LIN:
+                if (!st.lin_full) {   // the hot path wrote gradients only: bring the records up to date first
+                    if (int rl = do_linearize(st, true)) return rl;
+                }
+                return down_lin(dst, st.lin);
             case ILQR_TRIAL_COSTS: return down_tc(dst, st.costs, A, 1);
             case ILQR_COST: ILQR_HIPCHK(hipMemcpyAsync(dst, st.cost, bytes, hipMemcpyDeviceToHost, stream)); return sync();
             case ILQR_ALPHA: ILQR_HIPCHK(hipMemcpyAsync(dst, st.alpha_taken, bytes, hipMemcpyDeviceToHost, stream)); return sync();
@@ -737,8 +748,12 @@ template <typename T> class SolverT : public SolverBase {
     }
 
     // ---- stages ---------------------------------------------------------------------
-    int do_linearize(DeviceState<T>& s) {
+    // full = false: the sweep that follows may be the constant-matrix form, which reads the matrices at t = N-1 only
+    int do_linearize(DeviceState<T>& s, bool full = false) {
         KArgs<T> a = kargs(s);
+        const bool sparse = !full && ops.const_lin && ops.sweep_reads_sparse && ops.sweep_reads_sparse((T)cfg.mu);
+        a.lin_sparse = sparse ? 1 : 0;
+        s.lin_full = !sparse;
         timer.begin(ILQR_PHASE_LINEARIZE, stream);
         ops.linearize[cfg.integrator](a, stream);
         timer.end(stream);
@@ -984,6 +999,7 @@ template <typename T> class SolverT : public SolverBase {
         if ((rc = ensure_fn()) || (rc = reset_fn())) return rc;
         if ((rc = up_lin(lin, fn.lin))) return rc;
         fn.lin_const = false;    // caller-supplied tensors: anything goes
+        fn.lin_full = true;
         if (ops.tile16 && NX < 4) {
             // the sweep reads [V_x (4) | V_xx (4 x 4)] zero-padded
             std::vector<T> pad((size_t)B * 20, T(0));
