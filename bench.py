@@ -159,7 +159,12 @@ def main():
     ap.add_argument("--no-phase-timing", action="store_true")
     ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence / MPC extras (profiling runs)")
     ap.add_argument("--exchange", action="store_true",
-                    help="N = 1 only: run the per-step inter-GPU status exchange anyway, over a ONE-rank RCCL group")
+                    help="N = 1 only: run the inter-GPU status exchange anyway, over a ONE-rank RCCL group")
+    ap.add_argument("--exchange-every", type=int, default=0,
+                    help="iterations between two status exchanges (N > 1 or --exchange); 0 = once, behind the last of the "
+                         "K steps -- a solve needs the global status once, at its end, and no shard needs another shard's "
+                         "numbers to iterate.  One exchange costs the compute stream 25-50 us (status reduce, event, and a "
+                         "collective kernel sharing the CUs): measured with --exchange --exchange-every 1 / 4")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -221,21 +226,29 @@ def main():
     h.initial_rollout()
     xchg = StatusExchange(device=f"cuda:{local_rank}") if exchange else None
 
+    every = args.exchange_every if args.exchange_every > 0 else args.steps
+    count = [0]
+
     def step():
         h.iterate(1)
-        if exchange:
+        count[0] += 1
+        if exchange and count[0] % every == 0:
             # the path's only inter-GPU exchange: best cost / convergence, as one 32-B all-gather
             # over RCCL on a side stream, so the compute stream never waits for it
             xchg.launch(lambda t: h.status_reduce(t.data_ptr()))
 
     def fence():
-        if exchange:
+        if exchange and xchg.k:
             xchg.result()            # the last exchange has landed on every rank
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
+    if exchange:
+        # the collective's first call builds the RCCL communicator (tens of ms): it belongs to the warm-up
+        xchg.launch(lambda t: h.status_reduce(t.data_ptr()))
+    count[0] = 0
     fence()
     # ---- the timed region: exactly K steps, nothing else on the stream ------------------------------
     t0 = time.perf_counter()
@@ -289,7 +302,7 @@ def main():
                                    f"n=4 m=1 N=200 rk4, batch {B} trajectories per GPU, {args.n_alpha} parallel "
                                    "line-search alphas per pass covering the 10 reference trials, fixed iterations",
                        "batch_per_gpu": B, "horizon": N, "n_alpha": args.n_alpha, "n_trials": 10,
-                       "sharding": f"{world} independent shards, scalar all-reduce per step" if world > 1
+                       "sharding": f"{world} independent shards, scalar status all-gather every {every} steps (once per solve)" if world > 1
                        else "single shard"},
             "all_costs_finite": finite,
         }
@@ -328,7 +341,7 @@ def main():
                 out["cpu_baseline_all_cores"] = cpu_all
                 out["gpu_over_cpu_all_cores"] = value / cpu_all["value"]
         if exchange and world == 1:
-            out["exchange"] = "per-step status all-gather over a one-rank RCCL group (side stream)"
+            out["exchange"] = f"status all-gather over a one-rank RCCL group (side stream) every {every} steps"
         if world == 1 and not args.no_phase_timing and not args.no_solve_extra:
             # reported beside the throughput figure, outside every timed region above: the same batch
             # solved to convergence with the reference's stopping rules (tol, maxiter 50, line-search failure)

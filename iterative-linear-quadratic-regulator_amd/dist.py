@@ -85,7 +85,10 @@ class StatusExchange:
         self.k = 0
         if self.cuda:
             self.side = torch.cuda.Stream(device=dev)
-            self.done = [None, None]
+            # one event pair per buffer, re-recorded at every use (creating events per step is host time on a 0.2 ms step)
+            self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.used = [False, False]
 
     def launch(self, fill):
         """fill(stats_tensor) writes this rank's 4-vector ON TORCH'S CURRENT STREAM (e.g. handle.status_reduce of a
@@ -97,16 +100,17 @@ class StatusExchange:
         self.k += 1
         if self.cuda:
             cur = torch.cuda.current_stream()
-            if self.done[i] is not None:
-                cur.wait_event(self.done[i])      # the collective that last used this buffer pair has finished
+            # the collective that last used this buffer pair (two launches ago) must have finished: normally it has, and
+            # then the compute stream is spared the wait packet
+            if self.used[i] and not self.done[i].query():
+                cur.wait_event(self.done[i])
             fill(self.stats[i])
-            ready = torch.cuda.Event()
-            ready.record(cur)
+            self.ready[i].record(cur)
             with torch.cuda.stream(self.side):
-                self.side.wait_event(ready)
+                self.side.wait_event(self.ready[i])
                 self._gather(i)
-                self.done[i] = torch.cuda.Event()
                 self.done[i].record(self.side)
+            self.used[i] = True
         else:
             fill(self.stats[i])
             self._gather(i)
