@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 1
+#define ILQR_ABI_VERSION 2
 
 typedef struct ilqr_solver_s* ilqr_handle;
 
@@ -83,8 +83,10 @@ enum {
 };
 
 enum {
-    ILQR_FLAG_KEEP_ITERATING = 1 /* throughput mode: trajectories never leave ACTIVE (no convergence /
-                                    line-search break), so every iteration does the full batch's work */
+    ILQR_FLAG_KEEP_ITERATING = 1, /* throughput mode: trajectories never leave ACTIVE (no convergence /
+                                     line-search break), so every iteration does the full batch's work */
+    ILQR_FLAG_NO_FUSE = 2         /* keep linearise, sweep and acceptance step as separate launches over a materialised
+                                     expansion inside ilqr_iterate / ilqr_solve / ilqr_mpc_run (see ILQR_PHASE_FUSED) */
 };
 
 /*
@@ -148,7 +150,9 @@ enum {
     ILQR_PHASE_FORWARD = 2,
     ILQR_PHASE_SELECT = 3,
     ILQR_PHASE_OTHER = 4,
-    ILQR_N_PHASES = 5
+    ILQR_PHASE_FUSED = 5, /* acceptance step + linearisation + sweep as one kernel (the default inside ilqr_iterate /
+                             ilqr_solve / ilqr_mpc_run for the n_u = 1 DPP systems; ILQR_NO_FUSE=1 keeps the stages apart) */
+    ILQR_N_PHASES = 6
 };
 
 /* ---- library-level ------------------------------------------------------ */
@@ -193,8 +197,12 @@ int ilqr_forward(ilqr_handle h, const double* alphas, int n);
 /* backtracking acceptance "first alpha with cost_new <= cost" + convergence bookkeeping
  * (iLQR_class.py:267-271, 279-307) */
 int ilqr_select(ilqr_handle h);
-/* n_iters x (linearize, backward, forward over all trial alphas, select), no host sync */
+/* n_iters x (linearize, backward, forward over all trial alphas, select), no host sync.  The acceptance step of the
+ * LAST iteration may still be pending when the call returns (the next iteration's kernel runs it for its own
+ * trajectories); every entry point that reads or writes solver state completes it first, ilqr_flush does so explicitly. */
 int ilqr_iterate(ilqr_handle h, int n_iters);
+/* enqueue whatever bookkeeping ilqr_iterate deferred (iLQR_class.py:289-307 of its last iteration); asynchronous */
+int ilqr_flush(ilqr_handle h);
 
 /* ---- whole solve: iLQR.optimize_trajectory (iLQR_class.py:250-313), synchronous.
  *      iters_out [B] int32 and cost_out [B] (handle dtype) may be NULL. ------- */

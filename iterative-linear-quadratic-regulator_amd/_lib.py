@@ -28,15 +28,16 @@ INTEGRATORS = {"euler": 0, "midpoint": 1, "rk4": 2, "backward_euler": 3, "discre
 TRAJ_ACTIVE, TRAJ_CONVERGED, TRAJ_LINESEARCH_FAILED, TRAJ_MAXITER = range(4)
 TRAJ_FLAG_NON_PD = 0x100
 FLAG_KEEP_ITERATING = 1
-PHASES = ("linearize", "backward", "forward", "select", "other")
-ABI_VERSION = 1
+FLAG_NO_FUSE = 2
+PHASES = ("linearize", "backward", "forward", "select", "other", "fused")
+ABI_VERSION = 2
 
 # every symbol include/ilqr_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (
     "ilqr_abi_version", "ilqr_device_count", "ilqr_param_count", "ilqr_is_supported", "ilqr_last_error",
     "ilqr_create", "ilqr_create_custom", "ilqr_destroy", "ilqr_sync", "ilqr_set_problem", "ilqr_set", "ilqr_get",
     "ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_forward", "ilqr_select", "ilqr_iterate",
-    "ilqr_solve", "ilqr_backward_pass", "ilqr_backward_tensors", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
+    "ilqr_flush", "ilqr_solve", "ilqr_backward_pass", "ilqr_backward_tensors", "ilqr_forward_pass", "ilqr_eval_points", "ilqr_mpc_reset",
     "ilqr_mpc_rearm", "ilqr_mpc_run", "ilqr_status_reduce", "ilqr_timing_enable", "ilqr_timing_reset", "ilqr_timing_get", "ilqr_algorithmic_bytes",
 )
 
@@ -101,7 +102,7 @@ def load():
     lib.ilqr_set_problem.argtypes = [vp, vp, vp]
     lib.ilqr_set.argtypes = [vp, ci, vp, C.c_size_t]
     lib.ilqr_get.argtypes = [vp, ci, vp, C.c_size_t]
-    for name in ("ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_select", "ilqr_timing_reset"):
+    for name in ("ilqr_initial_rollout", "ilqr_linearize", "ilqr_backward", "ilqr_select", "ilqr_timing_reset", "ilqr_flush"):
         getattr(lib, name).argtypes = [vp]
     lib.ilqr_forward.argtypes = [vp, C.POINTER(cd), ci]
     lib.ilqr_iterate.argtypes = [vp, ci]
@@ -252,6 +253,10 @@ class Handle:
 
     def iterate(self, n=1):
         self._chk(self.lib.ilqr_iterate(self.h, int(n)))
+
+    def flush(self):
+        """Enqueue the acceptance step ilqr_iterate may have left pending (every state access does this by itself)."""
+        self._chk(self.lib.ilqr_flush(self.h))
 
     def solve(self):
         iters = np.empty(self.B, dtype=np.int32)

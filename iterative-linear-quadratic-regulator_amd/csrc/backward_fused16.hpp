@@ -1,0 +1,259 @@
+// backward_fused16.hpp -- acceptance step + linearisation + backward Riccati sweep as ONE kernel for the systems the
+// 16-lane DPP sweep serves (n_u = 1, 2 <= n_x <= 4; iLQR_class.py:289-307, 318-331, 79-161).
+//
+// Why: in the materialised path (linearize_kernel -> backward_tile16_kernel) the 157 MB tile tensor of the c3 shape is
+// written to HBM only to be read once a microsecond later, the sweep's four waves per CU issue a vector instruction in
+// about half of their cycles (a 200-step latency chain), and the acceptance step between two iterations is a launch of
+// its own.  Here one workgroup owns 16 trajectories from start to end:
+//   * threads 0..15 run the acceptance step of the previous iteration's candidates for their trajectory
+//     (select_candidates: the same code as select_kernel) -- no other workgroup ever touches these trajectories, so the
+//     bookkeeping needs no grid-wide ordering;
+//   * P producer waves (lane = trajectory x 4 consecutive time steps) evaluate the expansion of `unit` k = time steps
+//     N-1-4k .. N-4-4k with exactly the arithmetic of linearize_kernel (Stepper::step_jac, tile16_pack), move the
+//     accepted trajectory into slot 0 as linearize_kernel does, and hand the tiles over through a ring of RU units in
+//     LDS;
+//   * the four sweep waves (one per SIMD, 4 trajectories each, raised priority) run the DPP step of
+//     backward_tile16.hpp on tiles read from that ring, one tile of lookahead, and store the gains.
+// Synchronisation is workgroup-local and needs no barrier after the head of the kernel: LDS executes a wave's
+// instructions in program order, so "tile writes, then ready[slot] = k + 1" by a producer and "poll ready[slot], then
+// tile reads" by a sweep wave are ordered by the hardware; the compiler is kept from reordering them by empty asm
+// statements with a memory clobber (a release / acquire fence would also drain the sweep's outstanding gain stores).
+// A sweep wave publishes done[w] = k + 1 once every read of unit k has been issued; a producer overwrites ring slot
+// k % RU only when all four have passed unit k - RU.
+//
+// The tile tensor is never materialised: the kernel's HBM traffic is the trajectory (read, and written once when it
+// moves to slot 0) and the gains -- it is bound by vector-instruction issue, not by HBM, and bench.py reports it so.
+#pragma once
+
+namespace ilqr {
+
+template <typename T> struct FusedCfg;
+// P: producer waves; RU: ring slots (units of 4 time steps x 16 trajectories); TILE: scalars between two tiles in LDS
+// (48 + padding: the 16-byte writes of 8 neighbouring lanes then fall into distinct banks in fp32 -- 52 dwords; fp64 keeps
+// its tiles 32-byte aligned for the double4 reads of the sweep and takes a two-way conflict on the writes)
+template <> struct FusedCfg<float> { static constexpr int P = 8, RU = 8, TILE = 52; };
+template <> struct FusedCfg<double> { static constexpr int P = 4, RU = 4, TILE = 52; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
+constexpr int kFusedUnitSteps = 4;
+
+template <typename T> constexpr int fused_lds_bytes() {
+    return FusedCfg<T>::RU * kFusedUnitSteps * 16 * FusedCfg<T>::TILE * (int)sizeof(T) + (FusedCfg<T>::RU + 4 + 32 + 4) * 4;
+}
+template <typename T> constexpr int fused_threads() { return 256 + 64 * FusedCfg<T>::P; }
+
+// the sweep's view of a tile in LDS, and the step that consumes it
+template <typename T> struct FusedStep;
+template <> struct FusedStep<float> {
+    using Tile = TileQ;
+    static ILQR_DEV void load(Tile& t, const float* tp, int i, int j, int l16) {
+        const float4 s = *reinterpret_cast<const float4*>(tp + 4 * j);
+        const float4 v = *reinterpret_cast<const float4*>(tp + 32 + 4 * j);
+        t.skj[0] = s.x; t.skj[1] = s.y; t.skj[2] = s.z; t.skj[3] = s.w;
+        t.vj[0] = v.x; t.vj[1] = v.y; t.vj[2] = v.z; t.vj[3] = v.w;
+        t.a = tp[l16];
+        t.lxx = tp[16 + l16];
+        t.c = tp[32 + l16];
+    }
+    static ILQR_DEV void step(const Tile& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj, float& kff, bool& pd) {
+        RawTileQ none;            // (the refill arguments of the ring form are unused without REFILL)
+        const i32x4 srd = {0, 0, 0, 0};
+        const TileOffsets off = {0, 0, 0};
+        tile16_step_f32<false>(c, lc, V, vx, Kj, kff, pd, none, srd, off, 0);
+    }
+};
+template <> struct FusedStep<double> {
+    using Tile = Tile16<double>;
+    static ILQR_DEV void load(Tile& t, const double* tp, int i, int j, int l16) { tile16_load_lds(t, tp, i, j, l16); }
+    static ILQR_DEV void step(const Tile& c, const LaneConst<double>& lc, double& V, double& vx, double& Kj, double& kff, bool& pd) {
+        tile16_step<double, false>(c, lc, 0.0, V, vx, Kj, kff, pd);
+    }
+};
+
+ILQR_DEV void compiler_fence() { asm volatile("" ::: "memory"); }
+ILQR_DEV int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+ILQR_DEV void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <typename T, typename Dyn, int INTEG>
+__global__ void __launch_bounds__(fused_threads<T>()) backward_fused16_kernel(KArgs<T> a) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    static_assert(NU == 1 && NX >= 2 && NX <= 4, "the fused sweep serves the n_u = 1 DPP tile");
+    constexpr int P = FusedCfg<T>::P, RU = FusedCfg<T>::RU, TL = FusedCfg<T>::TILE, US = kFusedUnitSteps;
+    constexpr int UNIT = US * 16 * TL;           // scalars per ring slot
+    constexpr int R = gain_record(NX, 1);
+    using PL = ParamLayout<Dyn::NSYS, NX, NU>;
+    using V4 = typename Vec4<T>::type;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    T* ring = reinterpret_cast<T*>(fused_lds);
+    int* ready = reinterpret_cast<int*>(fused_lds + (size_t)RU * UNIT * sizeof(T));   // [RU] unit index + 1 held by the slot
+    int* done = ready + RU;                      // [4]  units fully read, per sweep wave
+    int* s_slot = done + 4;                      // [16] slot of the trajectory's current (X, U)
+    int* s_stat = s_slot + 16;                   // [16] status word after the acceptance step (-1: beyond the batch)
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * 16;
+    const size_t B = a.B;
+    const int N = a.N;
+
+    // ---- head: acceptance step of the previous iteration's candidates (iLQR_class.py:289-307), one lane per trajectory
+    if (wave == 0) {
+        bool still = false;
+        if (lane < 16) {
+            const int b = b0 + lane;
+            int slot = 0, st = -1;
+            if (b < a.B) {
+                if (a.fuse_select) {
+                    still = select_candidates(a, b, true, slot, st);
+                } else {
+                    st = a.status[b];
+                    slot = a.cur_slot[b];
+                }
+                // an active trajectory is moved to slot 0 below (linearize_kernel's canonicalisation); a finished one
+                // stays where its accepted candidate is
+                a.cur_slot[b] = traj_active(st) ? 0 : slot;
+            }
+            s_slot[lane] = slot;
+            s_stat[lane] = st;
+        } else if (lane < 16 + RU + 4) {
+            ready[lane - 16] = 0;     // ready[RU], done[4] are contiguous
+        }
+        if (a.fuse_select) {
+            const unsigned long long m = __ballot(still);
+            if (lane == 0 && m) atomicAdd(&a.counters[a.counter_idx], (int)__popcll(m));
+            if (blockIdx.x == 0 && lane == 0) a.counters[(a.counter_idx + 1) % kCounterRing] = 0;
+        }
+    }
+    __syncthreads();
+    bool any = false;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) any = any || traj_active(s_stat[q]);
+    if (!any) return;     // (uniform over the workgroup)
+
+    const int n_units = (N + US - 1) / US;
+    if (wave < 4) {
+        // ================= sweep: 4 trajectories per wave, lane (i, j) of a 16-lane row owns V_xx[i][j] ===============
+        __builtin_amdgcn_s_setprio(2);
+        const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
+        const int tl = 4 * wave + (lane >> 4);
+        const int gidx = b0 + tl;
+        const bool valid = gidx < a.B;
+        const int b = valid ? gidx : a.B - 1;
+        const int st = s_stat[tl];
+        const bool act = valid && traj_active(st);
+        const int slot = act ? s_slot[tl] : 0;
+        // terminal expansion at x_N of the accepted trajectory (iLQR_class.py:136-138), which also moves to slot 0
+        const T* __restrict__ pp = a.params;
+        T xN[NX];
+        vec_load<T, NX>(a.X + vec_at(B, N + 1, NX, slot, N, b), xN);
+        if (act && slot != 0 && l16 == 0) vec_store<T, NX>(a.X + vec_at(B, N + 1, NX, 0, N, b), xN);
+        T V = T(0), vx = T(0);
+        {
+            T g[NX], H[NX][NX];
+            Cost<T, Dyn>::l_f_x(pp, xN, g);
+            Cost<T, Dyn>::l_f_xx(pp, xN, H);
+#pragma unroll
+            for (int ii = 0; ii < NX; ++ii) {
+                if (j == ii) vx = g[ii];
+#pragma unroll
+                for (int jj = 0; jj < NX; ++jj)
+                    if (i == ii && j == jj) V = H[ii][jj];
+            }
+        }
+        const unsigned gain_bytes = (unsigned)((size_t)N * B * R * sizeof(T));
+        const __amdgpu_buffer_rsrc_t rgain = make_rsrc(a.gains, gain_bytes);
+        const int rstride = (int)(B * R * sizeof(T));
+        // lanes (0, j) store K[j], lane (1, 0) stores k; fp32: the others carry an offset beyond the descriptor's range
+        // and the hardware drops their store (backward_tile16_kernel)
+        constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
+        const bool storer = act && ((i == 0 && j < NX) || l16 == 4);
+        const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : NX)) * sizeof(T)) : 0x7ffffff0;
+        LaneConst<T> lc;
+        lc.m0 = T(j == 0);
+        lc.m1 = T(j == 1);
+        lc.tr_byte = 4 * ((lane & 48) | (j << 2) | i);
+        bool all_pd = true;
+        using FS = FusedStep<T>;
+        auto tile_ptr = [&](int s) -> const T* {
+            const int k = s / US, r = s % US;
+            return ring + (size_t)(k % RU) * UNIT + (r * 16 + tl) * TL;
+        };
+        auto wait_ready = [&](int k) {
+            while (lds_peek(&ready[k % RU]) < k + 1) __builtin_amdgcn_s_sleep(1);
+            compiler_fence();
+        };
+        typename FS::Tile cur, nxt;
+        wait_ready(0);
+        FS::load(cur, tile_ptr(0), i, j, l16);
+        nxt = cur;
+        int goff = (N - 1) * rstride;
+        for (int s0 = 0; s0 < N; s0 += US) {
+#pragma unroll
+            for (int r = 0; r < US; ++r) {
+                const int s = s0 + r;
+                if (s < N) {
+                    if (s + 1 < N) {
+                        if (r == US - 1) wait_ready((s + 1) / US);
+                        FS::load(nxt, tile_ptr(s + 1), i, j, l16);
+                    }
+                    T Kj, kff;
+                    bool pd;
+                    FS::step(cur, lc, V, vx, Kj, kff, pd);
+                    all_pd = all_pd && pd;
+                    if (DROP || storer) buf_store1(rgain, rec_off, uniform(goff), (i == 0) ? Kj : kff);
+                    goff -= rstride;
+                    cur = nxt;
+                }
+            }
+            // every read of this unit has been issued (LDS serves a wave in order): its ring slot may be overwritten
+            compiler_fence();
+            if (lane == 0) lds_poke(&done[wave], s0 / US + 1);
+        }
+        if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
+    } else {
+        // ================= producers: lane = (trajectory tl, time step r of the unit) ================================
+        const int pw = wave - 4;
+        const int tl = lane & 15, r = lane >> 4;
+        const int gidx = b0 + tl;
+        const bool valid = gidx < a.B;
+        const int b = valid ? gidx : a.B - 1;
+        const bool actb = valid && traj_active(s_stat[tl]);
+        const int slot = actb ? s_slot[tl] : 0;
+        const bool move = actb && slot != 0;
+        T p[PL::TOTAL];
+#pragma unroll
+        for (int q = 0; q < PL::TOTAL; ++q) p[q] = a.params[q];
+        for (int k = pw; k < n_units; k += P) {
+            const int t = N - 1 - k * US - r;
+            const bool inr = t >= 0;
+            const int tt = inr ? t : 0;
+            T x[NX], u[NU];
+            vec_load<T, NX>(a.X + vec_at(B, N + 1, NX, slot, tt, b), x);
+            vec_load<T, NU>(a.U + vec_at(B, N, NU, slot, tt, b), u);
+            if (move && inr) {
+                vec_store<T, NX>(a.X + vec_at(B, N + 1, NX, 0, tt, b), x);
+                vec_store<T, NU>(a.U + vec_at(B, N, NU, 0, tt, b), u);
+            }
+            T xn[NX], fx[NX][NX], fu[NX][NU];
+            Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);
+            V4 tile[12];
+            tile16_pack<T, Dyn>(p, a.dt, x, u, fx, fu, tile);
+            // the ring slot is free once every sweep wave has read unit k - RU
+            if (k >= RU) {
+                const int need = k - RU + 1;
+                while (min(min(lds_peek(&done[0]), lds_peek(&done[1])), min(lds_peek(&done[2]), lds_peek(&done[3]))) < need)
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            compiler_fence();
+            if (inr) {
+                constexpr int NQ = 12 * (int)sizeof(V4) / 16;       // 16-byte pieces of the tile
+                vec_u4 w[NQ];
+                __builtin_memcpy(w, tile, sizeof(V4) * 12);
+                vec_u4* dst = reinterpret_cast<vec_u4*>(ring + (size_t)(k % RU) * UNIT + (r * 16 + tl) * TL);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) dst[q] = w[q];
+            }
+            compiler_fence();
+            if (lane == 0) lds_poke(&ready[k % RU], k + 1);
+        }
+    }
+}
+
+}  // namespace ilqr

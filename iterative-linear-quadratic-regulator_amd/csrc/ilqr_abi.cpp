@@ -197,6 +197,7 @@ int ilqr_backward(ilqr_handle h) { ILQR_FWD(h, backward()); }
 int ilqr_forward(ilqr_handle h, const double* alphas, int n) { ILQR_FWD(h, forward(alphas, n)); }
 int ilqr_select(ilqr_handle h) { ILQR_FWD(h, select()); }
 int ilqr_iterate(ilqr_handle h, int n_iters) { ILQR_FWD(h, iterate(n_iters)); }
+int ilqr_flush(ilqr_handle h) { ILQR_FWD(h, flush()); }
 int ilqr_solve(ilqr_handle h, int32_t* iters_out, void* cost_out) { ILQR_FWD(h, solve(iters_out, cost_out)); }
 int ilqr_backward_pass(ilqr_handle h, const void* X, const void* U, void* U_ff_out, void* K_out) {
     ILQR_FWD(h, backward_pass(X, U, U_ff_out, K_out));

@@ -57,6 +57,7 @@ template <typename T> struct KArgs {
     int reset_slots;   // backward kernels: set cur_slot[b] = 0 for active b (after a canonicalising linearize)
     int const_lin;     // the expansion's matrices are the same at every (t, b) (a Linear system with the built-in quadratic
                        // cost: only l_x, l_u vary); set by the host for the library's own linearisation, never for caller tensors
+    int fuse_select;   // backward_fused16_kernel: run the acceptance step of the previous iteration's candidates first
     int lin_sparse;    // linearize_wave_kernel: write the constant matrices at t = N-1 only (what the CONST sweep reads), l_x, l_u everywhere
     const T* params;
     long long* probe;  // diagnostic: {shader cycles, 100 MHz ticks} of block 0 per kernel, or nullptr
@@ -136,6 +137,57 @@ struct ClockProbe {
 #include "backward_tile16.hpp"
 #include "backward_tile16m2.hpp"
 namespace ilqr {
+
+// ---------------------------------------------------------------------------
+// The expansion of one (b, t) point packed into the tile the DPP sweeps read: backward_tile16.hpp (n_u = 1: 48
+// scalars = 12 V4) or backward_tile16m2.hpp (n_x = 4, n_u = 2: 64 scalars = 16 V4).  fx, fu: the discrete Jacobians
+// (Stepper::step_jac); the cost derivatives are evaluated here.  n_x < 4 is zero-padded to the 4 x 4 tile (padding
+// states have no dynamics and no cost).  Shared by linearize_kernel and backward_fused16_kernel.
+// ---------------------------------------------------------------------------
+template <typename T, typename Dyn>
+ILQR_DEV void tile16_pack(const T* __restrict__ p, T dt, const T* x, const T* u, const T (*fx)[Dyn::NX],
+                          const T (*fu)[Dyn::NU], typename Vec4<T>::type* tile) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    static_assert((NX >= 2 && NX <= 4 && NU == 1) || (NX == 4 && NU == 2), "tile packing: n_x <= 4 with n_u = 1, or (4, 2)");
+    T gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
+    Cost<T, Dyn>::grad(p, dt, x, u, gxn, gu1);
+    Cost<T, Dyn>::hess(p, dt, x, u, lxxn, luxn, luu);
+    // zero-pad to the 4 x 4 tile (a no-op for n_x = 4): padding states have no dynamics and no cost
+    auto F = [&](int i, int j) -> T { return (i < NX && j < NX) ? fx[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
+    auto L = [&](int i, int j) -> T { return (i < NX && j < NX) ? lxxn[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        tile[c].x = F((c + 0) & 3, c); tile[c].y = F((c + 1) & 3, c);
+        tile[c].z = F((c + 2) & 3, c); tile[c].w = F((c + 3) & 3, c);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        tile[4 + i].x = L(i, 0); tile[4 + i].y = L(i, 1);
+        tile[4 + i].z = L(i, 2); tile[4 + i].w = L(i, 3);
+    }
+    if constexpr (NU == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int jj = j < NX ? j : 0;
+            tile[8 + j].x = j < NX ? fu[jj][0] : T(0);
+            tile[8 + j].y = j < NX ? gxn[jj] : T(0);
+            tile[8 + j].z = j < NX ? luxn[0][jj] : T(0);
+            tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
+        }
+    } else {
+        // group j: f_u[j][0], f_u[j][1], l_x[j], l_ux[0][j] | l_ux[1][j], e0, e1, e2   (backward_tile16m2.hpp);
+        // the sweep's Q_uu is symmetric: the mean of l_uu[0][1] and l_uu[1][0] is stored
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[8 + 2 * j].x = fu[j][0]; tile[8 + 2 * j].y = fu[j][NU - 1];
+            tile[8 + 2 * j].z = gxn[j]; tile[8 + 2 * j].w = luxn[0][j];
+            tile[9 + 2 * j].x = luxn[NU - 1][j];
+            tile[9 + 2 * j].y = (j == 0) ? gu1[0] : ((j == 1) ? T(0.5) * (luu[0][NU - 1] + luu[NU - 1][0]) : T(0));
+            tile[9 + 2 * j].z = (j == 0) ? gu1[NU - 1] : ((j == 1) ? luu[NU - 1][NU - 1] : T(0));
+            tile[9 + 2 * j].w = (j == 0) ? luu[0][0] : T(0);
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------
 // linearize: one lane per (b, t) point, t in [0, N]; t == N is the terminal
@@ -222,48 +274,10 @@ __global__ void __launch_bounds__(TILE16 ? 64 : 256) linearize_kernel(KArgs<T> a
         // lane's global index), but each lane holds ITS tile: a direct store would be TV x 16-B pieces at a
         // 192..512-B lane stride (measured 1.34x write amplification).  So the wave transposes through LDS in chunks
         // and writes 16 B per lane to consecutive addresses.
-        static_assert((NX >= 2 && NX <= 4 && NU == 1) || (NX == 4 && NU == 2), "tile packing: n_x <= 4 with n_u = 1, or (4, 2)");
         using V4 = typename Vec4<T>::type;
         constexpr int TV = NU == 1 ? 12 : 16;          // V4 per tile
-        T gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
-        Cost<T, Dyn>::grad(p, a.dt, x, u, gxn, gu1);
-        Cost<T, Dyn>::hess(p, a.dt, x, u, lxxn, luxn, luu);
-        // zero-pad to the 4 x 4 tile (a no-op for n_x = 4): padding states have no dynamics and no cost
-        auto F = [&](int i, int j) -> T { return (i < NX && j < NX) ? fx[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
-        auto L = [&](int i, int j) -> T { return (i < NX && j < NX) ? lxxn[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
         V4 tile[TV];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tile[c].x = F((c + 0) & 3, c); tile[c].y = F((c + 1) & 3, c);
-            tile[c].z = F((c + 2) & 3, c); tile[c].w = F((c + 3) & 3, c);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            tile[4 + i].x = L(i, 0); tile[4 + i].y = L(i, 1);
-            tile[4 + i].z = L(i, 2); tile[4 + i].w = L(i, 3);
-        }
-        if constexpr (NU == 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int jj = j < NX ? j : 0;
-                tile[8 + j].x = j < NX ? fu[jj][0] : T(0);
-                tile[8 + j].y = j < NX ? gxn[jj] : T(0);
-                tile[8 + j].z = j < NX ? luxn[0][jj] : T(0);
-                tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
-            }
-        } else {
-            // group j: f_u[j][0], f_u[j][1], l_x[j], l_ux[0][j] | l_ux[1][j], e0, e1, e2   (backward_tile16m2.hpp);
-            // the sweep's Q_uu is symmetric: the mean of l_uu[0][1] and l_uu[1][0] is stored
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                tile[8 + 2 * j].x = fu[j][0]; tile[8 + 2 * j].y = fu[j][NU - 1];
-                tile[8 + 2 * j].z = gxn[j]; tile[8 + 2 * j].w = luxn[0][j];
-                tile[9 + 2 * j].x = luxn[NU - 1][j];
-                tile[9 + 2 * j].y = (j == 0) ? gu1[0] : ((j == 1) ? T(0.5) * (luu[0][NU - 1] + luu[NU - 1][0]) : T(0));
-                tile[9 + 2 * j].z = (j == 0) ? gu1[NU - 1] : ((j == 1) ? luu[NU - 1][NU - 1] : T(0));
-                tile[9 + 2 * j].w = (j == 0) ? luu[0][0] : T(0);
-            }
-        }
+        tile16_pack<T, Dyn>(p, a.dt, x, u, fx, fu, tile);
         // two passes over groups of 32 whole tiles (so every pass writes one contiguous run of full cache lines).
         // One pass of 64 tiles in f32 needs 13 KB of LDS per wave and caps the kernel at 3 waves per SIMD; with
         // 6.6 KB it runs 4 (the VGPR limit) and hides more of its gather / store latency: 50 -> 46 us.
@@ -828,12 +842,72 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
 // (iLQR_class.py:289-297) over the candidates of one pass, and, on the last pass
 // of an iteration, the loop bookkeeping of optimize_trajectory (:267-271, :304-311).
 // ---------------------------------------------------------------------------
+// One trajectory's acceptance step over the candidates of a pass (non-init form).  Writes cost, cost_prev, alpha_taken
+// and -- on the last pass of an iteration -- iters, accepted and the new status; returns whether the trajectory is still
+// active.  slot_out = the slot its current trajectory lives in afterwards (the caller stores it: select_kernel as it
+// is, the fused sweep after moving the trajectory to slot 0); status_out = its status word afterwards.
+template <typename T>
+ILQR_DEV bool select_candidates(const KArgs<T>& a, int b, bool last_pass, int& slot_out, int& status_out) {
+    const size_t B = a.B;
+    int st = a.status[b];
+    int slot = a.cur_slot[b];
+    bool still_active = false;
+    if (traj_active(st)) {
+        int acc = a.accepted[b];
+        const T c0 = a.cost[b];
+        if (!acc) {
+            // all candidate costs are fetched before any is looked at: a first-match loop that loads as it
+            // goes serialises up to n_pass memory round trips (measured: most of this kernel's 8 us)
+            T cs[kMaxAlpha];
+#pragma unroll
+            for (int ai = 0; ai < kMaxAlpha; ++ai) cs[ai] = ai < a.n_pass ? a.costs[(size_t)ai * B + b] : T(0);
+            int first = -1;
+#pragma unroll
+            for (int ai = kMaxAlpha - 1; ai >= 0; --ai)
+                if (ai < a.n_pass && cs[ai] <= c0) first = ai;  // NaN compares false, like the reference
+            if (first >= 0) {
+                T c = cs[0], al = a.alphas[0];
+#pragma unroll
+                for (int ai = 1; ai < kMaxAlpha; ++ai)
+                    if (ai == first) { c = cs[ai]; al = a.alphas[ai]; }
+                slot = (slot + 1 + first) % a.n_slots;
+                a.cost_prev[b] = c0;
+                a.cost[b] = c;
+                a.alpha_taken[b] = al;
+                acc = 1;
+            }
+        }
+        if (last_pass) {
+            const int it = a.iters[b] + 1;
+            a.iters[b] = it;
+            a.accepted[b] = 0;
+            if (!(a.flags & ILQR_FLAG_KEEP_ITERATING)) {
+                if (!acc) {
+                    st = (st & ~0xff) | ILQR_TRAJ_LINESEARCH_FAILED;
+                } else if (it >= a.maxiter) {
+                    st = (st & ~0xff) | ILQR_TRAJ_MAXITER;
+                } else {
+                    const T d = M<T>::abs(a.cost[b] - a.cost_prev[b]);
+                    if (d <= a.tol) st = (st & ~0xff) | ILQR_TRAJ_CONVERGED;
+                }
+                a.status[b] = st;
+            }
+            if (!acc) a.alpha_taken[b] = T(0);
+        } else {
+            a.accepted[b] = acc;
+        }
+        still_active = traj_active(st);
+    }
+    slot_out = slot;
+    status_out = st;
+    return still_active;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) select_kernel(KArgs<T> a) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     bool still_active = false;
     if (b < a.B) {
-        const size_t B = a.B;
         if (a.init_mode) {
             // head of optimize_trajectory: X, U, cost <- forward_pass(alpha = 0)  (:257-259)
             const T c = a.costs[b];
@@ -846,53 +920,10 @@ __global__ void __launch_bounds__(256) select_kernel(KArgs<T> a) {
             a.accepted[b] = 0;
             still_active = true;
         } else {
-            int st = a.status[b];
-            if (traj_active(st)) {
-                int acc = a.accepted[b];
-                const T c0 = a.cost[b];
-                if (!acc) {
-                    // all candidate costs are fetched before any is looked at: a first-match loop that loads as it
-                    // goes serialises up to n_pass memory round trips (measured: most of this kernel's 8 us)
-                    T cs[kMaxAlpha];
-#pragma unroll
-                    for (int ai = 0; ai < kMaxAlpha; ++ai) cs[ai] = ai < a.n_pass ? a.costs[(size_t)ai * B + b] : T(0);
-                    int first = -1;
-#pragma unroll
-                    for (int ai = kMaxAlpha - 1; ai >= 0; --ai)
-                        if (ai < a.n_pass && cs[ai] <= c0) first = ai;  // NaN compares false, like the reference
-                    if (first >= 0) {
-                        T c = cs[0], al = a.alphas[0];
-#pragma unroll
-                        for (int ai = 1; ai < kMaxAlpha; ++ai)
-                            if (ai == first) { c = cs[ai]; al = a.alphas[ai]; }
-                        a.cur_slot[b] = (a.cur_slot[b] + 1 + first) % a.n_slots;
-                        a.cost_prev[b] = c0;
-                        a.cost[b] = c;
-                        a.alpha_taken[b] = al;
-                        acc = 1;
-                    }
-                }
-                if (a.last_pass) {
-                    const int it = a.iters[b] + 1;
-                    a.iters[b] = it;
-                    a.accepted[b] = 0;
-                    if (!(a.flags & ILQR_FLAG_KEEP_ITERATING)) {
-                        if (!acc) {
-                            st = (st & ~0xff) | ILQR_TRAJ_LINESEARCH_FAILED;
-                        } else if (it >= a.maxiter) {
-                            st = (st & ~0xff) | ILQR_TRAJ_MAXITER;
-                        } else {
-                            const T d = M<T>::abs(a.cost[b] - a.cost_prev[b]);
-                            if (d <= a.tol) st = (st & ~0xff) | ILQR_TRAJ_CONVERGED;
-                        }
-                        a.status[b] = st;
-                    }
-                    if (!acc) a.alpha_taken[b] = T(0);
-                } else {
-                    a.accepted[b] = acc;
-                }
-                still_active = traj_active(st);
-            }
+            int slot, st;
+            const int slot_before = a.cur_slot[b];
+            still_active = select_candidates(a, b, a.last_pass != 0, slot, st);
+            if (slot != slot_before) a.cur_slot[b] = slot;
         }
     }
     if (a.last_pass || a.init_mode) {
@@ -1150,3 +1181,4 @@ __global__ void gains_gather_k_kernel(T* denseUff, const T* gains, int B, int N,
 }
 
 }  // namespace ilqr
+#include "backward_fused16.hpp"

@@ -39,6 +39,7 @@ struct SolverBase {
     virtual int forward(const double* alphas, int n) = 0;
     virtual int select() = 0;
     virtual int iterate(int n) = 0;
+    virtual int flush() = 0;
     virtual int solve(int32_t* iters, void* cost) = 0;
     virtual int backward_pass(const void* X, const void* U, void* Uff, void* K) = 0;
     virtual int backward_tensors(const void* lin, const void* term, void* Uff, void* K) = 0;
@@ -91,6 +92,7 @@ template <typename T> struct Ops {
     void (*linearize[5])(const KArgs<T>&, hipStream_t) = {};  // indexed by ilqr_integrator
     void (*backward)(const KArgs<T>&, hipStream_t) = nullptr;
     void (*forward[5])(const KArgs<T>&, hipStream_t) = {};
+    void (*fused[5])(const KArgs<T>&, hipStream_t) = {};   // acceptance step + linearise + sweep in one launch (backward_fused16.hpp), or null
     void (*eval)(const EvalArgs<T>&, hipStream_t) = nullptr;
     void (*mpc_advance)(const MpcArgs<T>&, hipStream_t) = nullptr;
     int n_dev_params = 0;
@@ -117,6 +119,10 @@ template <typename T, int NX, int NU> struct has_fwd_in<T, NX, NU, decltype((voi
 #ifndef ILQR_RING_INTEG_MASK
 #define ILQR_RING_INTEG_MASK 0x1f
 #endif
+// Bit i set: integrator i gets the fused acceptance + linearise + sweep kernel (backward_fused16.hpp)
+#ifndef ILQR_FUSE_INTEG_MASK
+#define ILQR_FUSE_INTEG_MASK 0x1f
+#endif
 
 template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_ops(Ops<T>& o) {
     constexpr bool SMALL = all_integrators<Dyn>::value;
@@ -127,6 +133,20 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
         constexpr int TPB = TILE ? 64 : 256;
         ILQR_LAUNCH((linearize_kernel<T, Dyn, TILE, I>), dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, s, a);
     };
+    if constexpr (TILE && Dyn::NU == 1 && ((ILQR_FUSE_INTEG_MASK >> I) & 1)) {
+        o.fused[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
+            // one workgroup = 16 trajectories: 4 sweep waves + the producer waves, tiles through ~104 KB of LDS
+            static const bool ok = [] {
+                const bool r = hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T>()) == hipSuccess;
+                (void)hipGetLastError();
+                return r;
+            }();
+            (void)ok;
+            ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I>), dim3((a.B + 15) / 16), dim3(fused_threads<T>()),
+                        fused_lds_bytes<T>(), s, a);
+        };
+    }
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
         const dim3 grid((a.B + 63) / 64, a.n_pass), block(64);
         if constexpr (has_fwd_in<T, Dyn::NX, Dyn::NU>::value && ((ILQR_RING_INTEG_MASK >> I) & 1)) {
@@ -542,6 +562,7 @@ template <typename T> class SolverT : public SolverBase {
     }
 
     int sync() override {
+        if (int rf = flush_select()) return rf;
         ILQR_HIPCHK(hipStreamSynchronize(stream));
         return ILQR_OK;
     }
@@ -679,6 +700,7 @@ template <typename T> class SolverT : public SolverBase {
     // fresh solver as after iLQR.__init__ (iLQR_class.py:55-61)
     int set_problem(const void* x0, const void* U) override {
         if (!x0 || !U) { err = "set_problem: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        sel_pending = false;     // the state it would have updated is wiped
         int rc = zero_solver_state(st);
         if (rc) return rc;
         if ((rc = up_tc(x0, st.x0, NX, 1))) return rc;
@@ -708,6 +730,7 @@ template <typename T> class SolverT : public SolverBase {
         if (!src) { err = "set: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
         const size_t want = field_bytes(field);
         if (want == 0 || bytes != want) { err = "set: unknown field or wrong byte count"; return ILQR_ERR_INVALID_ARG; }
+        if (int rf = flush_select()) return rf;
         if (int rcs = fix_slots(st)) return rcs;
         switch (field) {
             case ILQR_X: return up_ct(src, st.X, st.cur_slot, NX, N + 1);
@@ -724,6 +747,7 @@ template <typename T> class SolverT : public SolverBase {
         if (!dst) { err = "get: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
         const size_t want = field_bytes(field);
         if (want == 0 || bytes != want) { err = "get: unknown field or wrong byte count"; return ILQR_ERR_INVALID_ARG; }
+        if (int rf = flush_select()) return rf;
         if (int rcs = fix_slots(st)) return rcs;
         switch (field) {
             case ILQR_X: return down_ct(dst, st.X, st.cur_slot, NX, N + 1);
@@ -733,7 +757,7 @@ template <typename T> class SolverT : public SolverBase {
             case ILQR_X0: return down_tc(dst, st.x0, NX, 1);
             case ILQR_PLANT_X: return down_tc(dst, plant_x, NX, 1);
             case ILQR_LIN:
-                if (!st.lin_full) {   // the hot path wrote gradients only: bring the records up to date first
+                if (!st.lin_full || lin_stale) {   // the hot path wrote gradients only, or nothing (fused): bring the records up to date first
                     if (int rl = do_linearize(st, true)) return rl;
                 }
                 return down_lin(dst, st.lin);
@@ -759,6 +783,7 @@ template <typename T> class SolverT : public SolverBase {
         timer.end(stream);
         s.slots_stale = ops.canonical;   // the sweep that follows resets cur_slot (KArgs::reset_slots)
         s.lin_const = ops.const_lin;
+        if (&s == &st) lin_stale = false;
         return check_launch();
     }
     // cur_slot must be truthful before anything but the backward sweep looks at it
@@ -807,9 +832,32 @@ template <typename T> class SolverT : public SolverBase {
     int pending_n = 0;
     double pending_alphas[kMaxAlpha];
 
+    // ---- the fused iteration (backward_fused16.hpp) -----------------------------------------------------------------
+    // An iteration is then TWO launches: [acceptance step of the previous candidates + linearise + sweep] and the
+    // rollouts.  The acceptance step of the newest candidates stays pending until the next fused launch runs it for its
+    // own trajectories, or until anything else looks at the solver state (flush_select: the stand-alone kernel).
+    bool sel_pending = false;
+    int sel_cidx = 0, sel_n = 0;
+    double sel_alphas[kMaxAlpha];
+    bool lin_stale = false;      // the expansion in HBM is not the current trajectory's (the fused kernel never writes it)
+
+    bool fused_ok() const {
+        static const bool off = getenv("ILQR_NO_FUSE") != nullptr;   // A/B switch, and bench.py's materialised leg
+        return !off && !force_unfused && !(cfg.flags & ILQR_FLAG_NO_FUSE) && ops.fused[cfg.integrator] && cfg.mu == 0.0 && (int)trial_alphas.size() <= A &&
+               (size_t)N * B * R * sizeof(T) < 0x7ffffff0ull;
+    }
+    bool force_unfused = false;
+    int flush_select() {
+        if (!sel_pending) return ILQR_OK;
+        sel_pending = false;
+        return do_select(st, sel_alphas, sel_n, true, false, sel_cidx);
+    }
+    int flush() override { return flush_select(); }
+
     int initial_rollout() override {
         if (!have_problem) { err = "initial_rollout before set_problem"; return ILQR_ERR_STATE; }
         int rc;
+        if ((rc = flush_select())) return rc;
         // All trajectories take part in the head of a solve, whatever their previous status: the rollout's init mode
         // ignores status / accepted and clears counter slot 0, the select's init mode rewrites status, iteration count
         // and accepted flag of every trajectory -- two launches, no memsets (an MPC step used to pay three).
@@ -822,17 +870,24 @@ template <typename T> class SolverT : public SolverBase {
     }
     int linearize() override {
         if (!have_problem) { err = "linearize before set_problem"; return ILQR_ERR_STATE; }
+        if (int rf = flush_select()) return rf;
         return do_linearize(st);
     }
     int backward() override {
         if (!have_problem) { err = "backward before set_problem"; return ILQR_ERR_STATE; }
+        if (int rf = flush_select()) return rf;
+        if (lin_stale) {      // the last iteration ran fused: there is no expansion in HBM to sweep over yet
+            if (int rl = do_linearize(st)) return rl;
+        }
         return do_backward(st);
     }
     int forward(const double* alphas, int n) override {
         if (!have_rollout) { err = "forward before initial_rollout"; return ILQR_ERR_STATE; }
         if (!alphas) { err = "forward: NULL alphas"; return ILQR_ERR_INVALID_ARG; }
         if (n < 1 || n > A) { err = "forward: alpha count must be in [1, n_alpha]"; return ILQR_ERR_INVALID_ARG; }
-        int rc = do_forward(st, alphas, n);
+        int rc = flush_select();
+        if (rc) return rc;
+        rc = do_forward(st, alphas, n);
         if (rc) return rc;
         pending_n = n;
         for (int i = 0; i < n; ++i) pending_alphas[i] = alphas[i];
@@ -854,6 +909,29 @@ template <typename T> class SolverT : public SolverBase {
     // number of trajectories still active after it
     int one_iteration(int* counter_idx, int forced_cidx = -1) {
         int rc;
+        if (fused_ok() && forced_cidx < 0) {
+            if ((rc = fix_slots(st))) return rc;
+            KArgs<T> a = kargs(st);
+            a.fuse_select = sel_pending ? 1 : 0;
+            a.n_pass = sel_n; a.last_pass = 1; a.counter_idx = sel_cidx;
+            for (int i = 0; i < sel_n; ++i) a.alphas[i] = (T)sel_alphas[i];
+            timer.begin(ILQR_PHASE_FUSED, stream);
+            ops.fused[cfg.integrator](a, stream);
+            timer.end(stream);
+            if ((rc = check_launch())) return rc;
+            sel_pending = false;
+            lin_stale = true;
+            const int n = (int)trial_alphas.size();
+            const int cidx = next_counter();
+            if ((rc = do_forward(st, trial_alphas.data(), n))) return rc;
+            sel_pending = true;
+            sel_cidx = cidx;
+            sel_n = n;
+            for (int i = 0; i < n; ++i) sel_alphas[i] = trial_alphas[i];
+            if (counter_idx) *counter_idx = cidx;
+            return ILQR_OK;
+        }
+        if ((rc = flush_select())) return rc;
         if ((rc = do_linearize(st))) return rc;
         if ((rc = do_backward(st))) return rc;
         const int total = (int)trial_alphas.size();
@@ -893,6 +971,7 @@ template <typename T> class SolverT : public SolverBase {
         static const bool want_graph = getenv("ILQR_USE_GRAPH") != nullptr;
         int i = 0;
         if (want_graph && graph_ok && !timer.on && n >= 1) {
+            force_unfused = true;      // the captured iteration is the four-launch form
             if (!iter_graph) {
                 // one ordinary iteration first: one-time function attributes must not be set inside a capture
                 int rc = one_iteration(nullptr);
@@ -933,7 +1012,27 @@ template <typename T> class SolverT : public SolverBase {
         if (cfg.maxiter <= enqueue_all) {
             for (int i = 0; i < cfg.maxiter; ++i)
                 if ((rc = one_iteration(nullptr))) return rc;
-            return ILQR_OK;
+            return flush_select();
+        }
+        if (fused_ok()) {
+            // The count of trajectories still active after iteration i is written by the kernel that runs its
+            // acceptance step: the fused launch of iteration i + 1.  It is copied out right behind that launch's
+            // iteration and looked at one iteration later still, so the stream never drains for the read-back (the
+            // price is two surplus iterations of early-exiting kernels at the end of a solve instead of one).
+            int cidx_of[3] = {-1, -1, -1};     // counter slot of iterations i, i-1, i-2
+            for (int i = 0; i < cfg.maxiter; ++i) {
+                cidx_of[2] = cidx_of[1]; cidx_of[1] = cidx_of[0];
+                if ((rc = one_iteration(&cidx_of[0]))) return rc;
+                if (i >= 1) {
+                    ILQR_HIPCHK(hipMemcpyAsync(h_counter + cidx_of[1], st.counters + cidx_of[1], sizeof(int), hipMemcpyDeviceToHost, stream));
+                    ILQR_HIPCHK(hipEventRecord(loop_ev[i & 1], stream));
+                }
+                if (i >= 2) {
+                    ILQR_HIPCHK(hipEventSynchronize(loop_ev[(i - 1) & 1]));
+                    if (h_counter[cidx_of[2]] == 0) { sel_pending = false; break; }   // nobody is active: nothing left to accept
+                }
+            }
+            return flush_select();
         }
         int prev = -1;
         for (int i = 0; i < cfg.maxiter; ++i) {
@@ -1098,6 +1197,7 @@ template <typename T> class SolverT : public SolverBase {
         if (!x0 || !U) { err = "mpc_rearm: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
         if (!have_problem) { err = "mpc_rearm before set_problem / mpc_reset"; return ILQR_ERR_STATE; }
         int rc;
+        if ((rc = flush_select())) return rc;
         if ((rc = fix_slots(st))) return rc;
         if ((rc = up_tc(x0, st.x0, NX, 1))) return rc;
         if ((rc = up_tc(x0, plant_x, NX, 1))) return rc;
@@ -1152,6 +1252,7 @@ template <typename T> class SolverT : public SolverBase {
 
     int status_reduce(void* dev_out4) override {
         if (!dev_out4) { err = "status_reduce: NULL pointer"; return ILQR_ERR_INVALID_ARG; }
+        if (int rf = flush_select()) return rf;
         timer.begin(ILQR_PHASE_OTHER, stream);
         ILQR_LAUNCH(status_reduce_kernel<T>, dim3(1), dim3(256), 0, stream, st.cost, st.cost_prev, st.status, B,
                            (double*)dev_out4);
@@ -1178,6 +1279,8 @@ template <typename T> class SolverT : public SolverBase {
         bytes[ILQR_PHASE_FORWARD] = b * Nn * s * ((n + 2 * m + m * n) + (double)A * (n + m));
         bytes[ILQR_PHASE_SELECT] = b * (s * (A + 3) + 4 * 4);
         bytes[ILQR_PHASE_OTHER] = 0;
+        // the fused kernel materialises no expansion: it reads the trajectory and the candidates' costs, writes the gains
+        bytes[ILQR_PHASE_FUSED] = b * s * (Nn * ((n + m) + (m * n + m)) + n) + bytes[ILQR_PHASE_SELECT];
         return ILQR_OK;
     }
 };

@@ -1,0 +1,22 @@
+"""Fused iteration (backward_fused16_kernel + rollout) against the materialised one (linearise, sweep, rollout, select)
+at the UA double pendulum shapes: wall per iteration and per-kernel HIP-event times."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ilqr_amd
+from ilqr_amd import _lib, problems
+
+p = problems.ua_double_pendulum()
+dts = [np.float32, np.float64] if "--f64" in sys.argv else [np.float32]
+for dt in dts:
+    for B in (4096, 1024, 256):
+        x0, U0 = problems.ua_batch(B, seed=0)
+        for tag, fl in (("fused", 0), ("materialised", _lib.FLAG_NO_FUSE)):
+            h = ilqr_amd.make_system(p["dynamics"], p["cost"], dt).make_handle(
+                horizon=200, batch=B, n_alpha=10, maxiter=1 << 30, flags=_lib.FLAG_KEEP_ITERATING | fl)
+            h.set_problem(x0, U0); h.initial_rollout(); h.iterate(5); h.sync()
+            t0 = time.perf_counter(); h.iterate(20); h.sync(); wall = (time.perf_counter() - t0) / 20
+            h.timing_enable(True); h.timing_reset(); h.iterate(20); h.flush()
+            ph = {k: round(v[0] / 20 * 1e3, 1) for k, v in h.timing_get().items() if v[1]}
+            print(f"{np.dtype(dt).name} B={B} {tag}: {wall*1e6:.1f} us/iteration = {B/wall/1e6:.2f} M it/s {ph}", flush=True)
+            h.close()
