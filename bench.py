@@ -36,7 +36,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
-PHASE_KERNEL = {"linearize": "linearize_kernel", "backward": "backward_tile16_kernel", "forward": "forward_ring_kernel"}
+PHASE_KERNEL = {"linearize": "linearize_kernel", "backward": "backward_tile16_kernel", "forward": "forward_ring_kernel",
+                "fused": "backward_fused16_kernel"}
 
 
 def pmc_traffic(dtype, batch, horizon):
@@ -125,10 +126,101 @@ def cpu_baseline(p, dtype, cores, budget_s=10.0, total_core_seconds=None):
                       f"reference loop with its sequential backtracking; {cores} worker processes, {wall:.1f} s"}
 
 
-def mpc_c4_extra(ilqr_amd, _lib, problems, np_dt, device, stream, B=1024, n_sim=10):
+def kernel_table(phases, ab, traffic, names, peak=HBM_PEAK_GBS):
+    """{kernel: {avg_launch_us, launches, algorithmic_bytes_per_launch, achieved_GBs, frac_of_8TBs, traffic}} from the
+    handle's per-dispatch HIP events (phases: {phase: (ms, launches)}) and its algorithmic byte counts."""
+    out = {}
+    for ph, kern in names.items():
+        ms_k, n_k = phases.get(ph, (0.0, 0))
+        if not n_k:
+            continue
+        ach = ab[ph] / (ms_k / n_k * 1e-3) / 1e9
+        out[kern] = {"avg_launch_us": ms_k / n_k * 1e3, "launches": n_k, "algorithmic_bytes_per_launch": ab[ph],
+                     "achieved_GBs": ach, "frac_of_8TBs": ach / peak, "traffic": (traffic or {}).get(ph)}
+    return out
+
+
+def pmc_valu(dtype, batch, horizon):
+    """Vector instructions per launch of the hot kernels (SQ_INSTS_VALU, summed over the waves of a launch) from the
+    newest committed profiles/rNN/pmc_valu_<dtype>.json of the same shape, or None."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_valu_{dtype}.json"))):
+        try:
+            d = json.load(open(path))
+            if d.get("batch") == batch and d.get("horizon") == horizon:
+                best = ({k: float(v["SQ_INSTS_VALU_per_launch"]) for k, v in d["kernels"].items()}, os.path.relpath(path, ROOT))
+        except Exception:
+            pass
+    return best
+
+
+def timed_iterations(h, steps, warm=3):
+    """(wall seconds per iteration, {phase: (ms, launches)}) of `steps` iterations on a handle whose problem is set."""
+    h.initial_rollout()
+    h.iterate(warm)
+    h.sync()
+    t0 = time.perf_counter()
+    h.iterate(steps)
+    h.sync()                      # (completes the last iteration's acceptance step too)
+    wall = (time.perf_counter() - t0) / steps
+    h.timing_enable(True)
+    h.timing_reset()
+    h.iterate(steps)
+    h.flush()
+    ph = h.timing_get()
+    h.timing_enable(False)
+    return wall, ph
+
+
+FUSED_NAMES = {"fused": "backward_fused16_kernel", "forward": "forward_ring_kernel", "linearize": "linearize_kernel",
+               "backward": "backward_tile16_kernel", "select": "select_kernel"}
+C5_NAMES = {"linearize": "linearize_wave_kernel", "backward": "backward_mfma16_kernel", "forward": "forward_mfma16_kernel",
+            "select": "select_kernel"}
+
+
+def config_extras(ilqr_amd, _lib, problems, device, stream, steps=10):
+    """The other BASELINE configs on this GPU, outside every timed region of the headline: per-iteration time,
+    iterations/sec and the per-kernel roofline table (algorithmic bytes of SURVEY 8d / HIP-event launch time), fixed
+    iterations (ILQR_FLAG_KEEP_ITERATING) like the headline.  c1 as the driver runs it (N = 400, backward Euler, B = 1),
+    c2 (B = 256), the c5 shard (B = 128) and c5 whole (B = 1024), c3 in fp64."""
+    out = {}
+
+    def run(tag, sysm, x0, U0, N, names, what):
+        h = sysm.make_handle(horizon=N, batch=len(x0), n_alpha=10, n_trials=10, maxiter=1 << 30, device=device,
+                             flags=_lib.FLAG_KEEP_ITERATING, stream=stream)
+        h.set_problem(x0, U0)
+        wall, ph = timed_iterations(h, steps)
+        ab = h.algorithmic_bytes()
+        out[tag] = {"workload": what, "batch": len(x0), "horizon": N, "dtype": "f32" if sysm.dtype == np.float32 else "f64",
+                    "ms_per_iteration": wall * 1e3, "iterations_per_sec": len(x0) / wall,
+                    "phases_us_per_iteration": {k: 1e3 * v[0] / steps for k, v in ph.items() if v[1]},
+                    "kernels": kernel_table(ph, ab, None, names)}
+        h.close()
+
+    p = problems.pendulum_open_loop(integrator="backward_euler", N=400)
+    run("c1", ilqr_amd.make_system(p["dynamics"], p["cost"], np.float32), p["x0"][None], p["U_init"][None], 400, FUSED_NAMES,
+        "pendulum n=2 m=1, N=400 backward_euler, batch 1 (run_iLQR_open_loop.py:16-69)")
+    p = problems.ua_double_pendulum()
+    x0, U0 = problems.ua_batch(256, seed=0)
+    run("c2", ilqr_amd.make_system(p["dynamics"], p["cost"], np.float32), x0, U0, 200, FUSED_NAMES,
+        "UA double pendulum n=4 m=1, N=200 rk4, batch 256")
+    x0, U0 = problems.ua_batch(4096, seed=1000)
+    run("c3_f64", ilqr_amd.make_system(p["dynamics"], p["cost"], np.float64), x0, U0, 200, FUSED_NAMES,
+        "the headline workload in fp64")
+    p = problems.linear_quadratic()
+    for B, tag in ((128, "c5_shard"), (1024, "c5")):
+        x0, U0 = problems.lq_batch(B, 16, 8, 500)
+        run(tag, ilqr_amd.make_system(p["dynamics"], p["cost"], np.float32), x0, U0, 500, C5_NAMES,
+            f"synthetic linear-quadratic n=16 m=8, N=500, batch {B}" + (" (one GPU's share of 1024 over 8)" if B == 128 else ""))
+    return out
+
+
+def mpc_extra(ilqr_amd, _lib, problems, np_dt, device, stream, B=1024, n_sim=10):
     """BASELINE config c4 at one GPU's shard, reported beside the headline (outside every timed region above): 1024
     warm-started MPC instances of the under-actuated double pendulum, N = 200, rk4 optimiser, backward_euler plant,
-    tol 1e-5, maxiter 50 (run_iLQR_UA_MPC.py:17-174), `n_sim` receding-horizon steps device-resident (ilqr_mpc_run)."""
+    tol 1e-5, maxiter 50 (run_iLQR_UA_MPC.py:17-174), `n_sim` receding-horizon steps device-resident (ilqr_mpc_run),
+    with the step's attribution from the per-dispatch HIP events of a second run of the same steps."""
     p = problems.ua_double_pendulum(N=200)
     x0, U0 = problems.ua_batch(B, seed=2, restarts=False, N=200)
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
@@ -140,10 +232,118 @@ def mpc_c4_extra(ilqr_amd, _lib, problems, np_dt, device, stream, B=1024, n_sim=
     u, x, c = h.mpc_run(n_sim)         # returns after the logs have been copied back (synchronous)
     wall = time.perf_counter() - t0
     its = h.get(_lib.ITERS)
+    h.timing_enable(True)
+    h.timing_reset()
+    t0 = time.perf_counter()
+    h.mpc_run(n_sim)
+    wall_t = time.perf_counter() - t0
+    ph = h.timing_get()
+    h.timing_enable(False)
     h.close()
+    busy_ms = sum(v[0] for v in ph.values())
+    launches = {k: v[1] for k, v in ph.items() if v[1]}
+    per_launch = {k: 1e3 * v[0] / v[1] for k, v in ph.items() if v[1]}
+    n_iter_launch = max(ph.get("fused", (0, 0))[1], ph.get("backward", (0, 0))[1])
     return {"instances": B, "horizon": 200, "maxiter": p["maxiter"], "steps": n_sim, "ms_per_mpc_step": 1e3 * wall / n_sim,
             "instance_steps_per_sec": B * n_sim / wall, "iterations_last_step_mean": float(np.mean(its)),
-            "iterations_last_step_max": int(np.max(its)), "all_finite": bool(np.isfinite(c).all())}
+            "iterations_last_step_max": int(np.max(its)), "all_finite": bool(np.isfinite(c).all()),
+            "attribution": {"iteration_launches_per_step": n_iter_launch / n_sim,
+                            "kernel_us_per_launch": per_launch, "launches_per_step": {k: v / n_sim for k, v in launches.items()},
+                            "kernel_busy_ms_per_step": busy_ms / n_sim,
+                            "host_and_gaps_ms_per_step": 1e3 * wall_t / n_sim - busy_ms / n_sim,
+                            "note": "a step lasts until its slowest instance has converged: iteration launches per step x "
+                                    "(fused + rollout) + one plant step; `phases` = HIP-event time of every dispatch of a second "
+                                    "run of the same steps; 'other' = the plant step (mpc_advance_kernel)"}}
+
+
+def run_c4(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist):
+    """BASELINE c4: 8192 warm-started MPC instances of the UA double pendulum (run_iLQR_UA_MPC.py:146-174), sharded
+    over the ranks (shard_range: 1024 per GPU at 8), device-resident; a step = one receding-horizon step of every
+    instance.  The only exchange is the scalar status all-reduce behind the timed steps (ShardedBatch.global_status)."""
+    from ilqr_amd.dist import ShardedBatch
+    total = args.batch if args.batch else 8192
+    p = problems.ua_double_pendulum(N=200)
+    x0, U0 = problems.ua_batch(total, seed=2, restarts=False, N=200)
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    plant = ilqr_amd.make_system(dict(p["dynamics"], integrator=p["plant_integrator"]), p["cost"], np_dt)
+    sb = ShardedBatch(lambda: ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt), x0.astype(np_dt), U0.astype(np_dt),
+                      device=local_rank, N=200, tol=p["tol"], maxiter=p["maxiter"], plant=plant, n_alpha=10)
+    sb.mpc_reset()
+    sb.mpc_run(max(args.warmup, 1))       # cold start: the first solves run to maxiter
+    if world > 1 or dist.is_initialized():
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    u, x, c = sb.mpc_run(args.steps)
+    st = sb.global_status()
+    if world > 1 or dist.is_initialized():
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "MPC instance-steps/sec (8192 warm-started UA double pendulum instances, T=200, n=4 m=1)",
+            "value": total * args.steps / wall, "unit": "MPC instance-steps/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "c4: 8192 MPC instances (run_iLQR_UA_MPC.py), rk4 optimiser, backward_euler plant, tol 1e-5, "
+                                   "maxiter 50, device-resident receding-horizon loop", "instances": total,
+                       "instances_per_gpu": sb.hi - sb.lo, "horizon": 200,
+                       "sharding": f"{world} contiguous shards (dist.shard_range), one scalar status all-reduce behind the steps"},
+            "global_status": {"min_cost": st.min_cost, "n_active": st.n_active, "n_converged": st.n_converged},
+            "all_costs_finite": bool(np.isfinite(c).all())}))
+
+
+def run_c5(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist):
+    """BASELINE c5: synthetic linear-quadratic system n=16 m=8, N=500, 1024 trajectories sharded over the ranks (128
+    per GPU at 8); a step = one iLQR iteration of the shard (MFMA sweep + MFMA rollouts), fixed iterations."""
+    from ilqr_amd.dist import shard_range
+    total = args.batch if args.batch else 1024
+    lo, hi = shard_range(total, world, rank)
+    p = problems.linear_quadratic()
+    x0, U0 = problems.lq_batch(total, 16, 8, 500)
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    h = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt).make_handle(
+        horizon=500, batch=hi - lo, n_alpha=10, n_trials=10, maxiter=1 << 30, device=local_rank,
+        flags=_lib.FLAG_KEEP_ITERATING, stream=tstream.cuda_stream)
+    h.set_problem(x0[lo:hi], U0[lo:hi])
+    h.initial_rollout()
+    h.iterate(args.warmup)
+    stats = torch.zeros(4, dtype=torch.float64, device="cuda")
+    from ilqr_amd.dist import allreduce_status, to_status
+    if world > 1 or dist.is_initialized():
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    h.iterate(args.steps)
+    h.status_reduce(stats.data_ptr())
+    allreduce_status(stats)
+    if world > 1 or dist.is_initialized():
+        dist.barrier(device_ids=[local_rank])
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
+    wall = float(wall_t.item())
+    st = to_status(stats.cpu())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "iLQR iterations/sec (synthetic LQ n=16 m=8, T=500, batch=1024)",
+            "value": total * args.steps / wall, "unit": "iLQR iterations/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "c5: synthetic linear-quadratic system n=16 m=8 N=500, fixed iterations", "batch": total,
+                       "batch_per_gpu": hi - lo, "horizon": 500, "n_alpha": 10,
+                       "sharding": f"{world} contiguous shards (dist.shard_range), one scalar status all-reduce behind the steps"},
+            "global_status": {"min_cost": st.min_cost, "n_active": st.n_active}}))
+    h.close()
 
 
 def main():
@@ -151,13 +351,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--config", default="c3", choices=["c3", "c4", "c5"],
+                    help="c3 = the headline (BASELINE metric); c4 = 8192 MPC instances, c5 = LQ n=16 m=8 batch 1024: both "
+                         "sharded over the ranks of torch.distributed.run, lines of their own")
+    ap.add_argument("--batch", type=int, default=0, help="c3: trajectories per GPU (4096); c4 / c5: total over all ranks")
     ap.add_argument("--n-alpha", type=int, default=10)
     ap.add_argument("--dtype", default="f32", choices=["f64", "f32"],
                     help="f32 = the reference's own (JAX default) precision; f64 = the build's double mode")
+    ap.add_argument("--materialised", action="store_true",
+                    help="time the four-launch iteration over the materialised expansion (ILQR_FLAG_NO_FUSE) instead of the fused one")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true")
-    ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence / MPC extras (profiling runs)")
+    ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence / MPC / configs extras (profiling runs)")
     ap.add_argument("--exchange", action="store_true",
                     help="N = 1 only: run the inter-GPU status exchange anyway, over a ONE-rank RCCL group")
     ap.add_argument("--exchange-every", type=int, default=0,
@@ -176,7 +381,7 @@ def main():
     p = problems.ua_double_pendulum(integrator="rk4", N=200)
     # CPU baseline first: its worker processes are forked before this process touches the GPU
     cpu = cpu_all = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.config == "c3":
         share, every = host_cores()
         cpu = cpu_baseline(p, args.dtype, share)
         cpu["numpy_restatement_single_core_value"] = numpy_restatement_rate(p, args.dtype)
@@ -201,16 +406,22 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")  # RCCL
-    elif args.exchange:
+    elif args.exchange or args.config != "c3":
+        # one rank: the collectives of the sharded configs still go through RCCL (a group of ONE rank)
         import socket
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
         dist.init_process_group("nccl", rank=0, world_size=1)
+    if args.config != "c3":
+        (run_c4 if args.config == "c4" else run_c5)(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist)
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+        return
     exchange = world > 1 or args.exchange
 
     np_dt = np.float64 if args.dtype == "f64" else np.float32
-    B, N = args.batch, p["N"]
+    B, N = (args.batch or 4096), p["N"]
     x0, U0 = problems.ua_batch(B, seed=1000 + rank, restarts=False, N=N)
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
     # launch on an explicit torch stream (made current) so torch's barriers, synchronize() and events see
@@ -220,8 +431,9 @@ def main():
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream, "expected a non-null HIP stream from torch"
+    path_flags = _lib.FLAG_NO_FUSE if args.materialised else 0
     h = sysm.make_handle(horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=1 << 30,
-                         device=local_rank, flags=_lib.FLAG_KEEP_ITERATING, stream=stream)
+                         device=local_rank, flags=_lib.FLAG_KEEP_ITERATING | path_flags, stream=stream)
     h.set_problem(x0, U0)       # uploads: inputs are HBM-resident from here on
     h.initial_rollout()
     xchg = StatusExchange(device=f"cuda:{local_rank}") if exchange else None
@@ -238,6 +450,7 @@ def main():
             xchg.launch(lambda t: h.status_reduce(t.data_ptr()))
 
     def fence():
+        h.flush()                    # the acceptance step of the newest candidates, if the last launch left it pending
         if exchange and xchg.k:
             xchg.result()            # the last exchange has landed on every rank
             dist.barrier(device_ids=[local_rank])
@@ -250,7 +463,8 @@ def main():
         xchg.launch(lambda t: h.status_reduce(t.data_ptr()))
     count[0] = 0
     fence()
-    # ---- the timed region: exactly K steps, nothing else on the stream ------------------------------
+    # ---- the timed region: exactly K steps (each: acceptance of the previous candidates, linearise, sweep, all
+    # rollouts), closed by the acceptance step of the last one; nothing else on the stream --------------------------
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -260,29 +474,39 @@ def main():
     # ---- per-phase breakdown: the same K steps again with HIP start/stop events attached to every kernel
     # dispatch (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, no extra stream packets)
     phases = None
-    bwd_us = None
+    mat = None
     if not args.no_phase_timing:
         h.timing_enable(True)
         h.timing_reset()
         for _ in range(args.steps):
             h.iterate(1)
+        h.flush()
         phases = h.timing_get()
         h.timing_enable(False)
-        # ---- extra: R back-to-back launches of the backward sweep on the same expansion (idempotent: reads
-        # lin/term, rewrites the same gains) between ONE pair of torch events on this stream.  It runs
-        # faster than inside the iteration (its tiles are then still cached from the previous launch instead
-        # of being freshly written by linearise) and is reported separately, not used for the roofline.
+        # ---- the materialised path beside it (outside the timed region): linearize_kernel -> backward_tile16_kernel ->
+        # rollouts -> select_kernel over the expansion in HBM, the form SURVEY 8(d)'s byte count describes.  Same
+        # problem, same K steps; plus R back-to-back launches of the sweep on one expansion (its tiles are then
+        # still cached from the previous launch instead of freshly written by linearise: reported separately).
+        hm = h if args.materialised else sysm.make_handle(
+            horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=1 << 30, device=local_rank,
+            flags=_lib.FLAG_KEEP_ITERATING | _lib.FLAG_NO_FUSE, stream=stream)
+        if hm is not h:
+            hm.set_problem(x0, U0)
+        wall_m, ph_m = (wall / args.steps, phases) if args.materialised else timed_iterations(hm, args.steps, warm=args.warmup)
         R = 50
-        h.linearize()
+        hm.linearize()
         for _ in range(5):
-            h.backward()
+            hm.backward()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(R):
-            h.backward()
+            hm.backward()
         e1.record()
         torch.cuda.synchronize()
-        bwd_us = e0.elapsed_time(e1) * 1e3 / R
+        mat = {"wall_s_per_step": wall_m, "phases": ph_m, "bwd_us_back_to_back": e0.elapsed_time(e1) * 1e3 / R,
+               "ab": hm.algorithmic_bytes()}
+        if hm is not h:
+            hm.close()
 
     wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -293,6 +517,9 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / wall
+        path = ("materialised: linearize_kernel, backward_tile16_kernel, forward_ring_kernel, select_kernel (4 launches)"
+                if args.materialised else
+                "fused: backward_fused16_kernel (acceptance step + linearise + sweep, tiles through LDS), forward_ring_kernel (2 launches)")
         out = {
             "metric": "iLQR iterations/sec (batch=4096, T=200, n=4 m=1); backward-pass HBM GB/s",
             "value": value, "unit": "iLQR iterations/sec", "n_gpus": world, "steps": args.steps,
@@ -301,35 +528,59 @@ def main():
             "config": {"workload": "c3: under-actuated double pendulum swing-up (run_iLQR_UA_MPC.py params), "
                                    f"n=4 m=1 N=200 rk4, batch {B} trajectories per GPU, {args.n_alpha} parallel "
                                    "line-search alphas per pass covering the 10 reference trials, fixed iterations",
-                       "batch_per_gpu": B, "horizon": N, "n_alpha": args.n_alpha, "n_trials": 10,
+                       "batch_per_gpu": B, "horizon": N, "n_alpha": args.n_alpha, "n_trials": 10, "iteration_path": path,
                        "sharding": f"{world} independent shards, scalar status all-gather every {every} steps (once per solve)" if world > 1
                        else "single shard"},
             "all_costs_finite": finite,
         }
         if phases is not None:
             ab = h.algorithmic_bytes()
-            ms, n = phases["backward"]
-            avg_s = ms / max(n, 1) * 1e-3      # in-iteration launches of the profiled K steps
-            achieved = ab["backward"] / avg_s / 1e9
             tr = pmc_traffic(args.dtype, B, N)
-            out["roofline"] = {"bound": "hbm", "kernel": "backward Riccati sweep (backward_tile16_kernel)",
-                               "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": tr[0].get("backward") if tr else None,
-                               "traffic_source": tr[1] if tr else None,
-                               "algorithmic_bytes_per_launch": ab["backward"], "avg_launch_us": avg_s * 1e6,
-                               "launches": n, "avg_launch_us_back_to_back": bwd_us,
-                               "frac_of_measured_copy_peak_6.29TBs": achieved / 6290.0}
             out["phases_us_per_step"] = {k: 1e3 * v[0] / args.steps for k, v in phases.items()}
-            # the same accounting for every hot kernel: algorithmic bytes / its average launch
-            out["kernels"] = {}
-            for ph, kern in PHASE_KERNEL.items():
-                ms_k, n_k = phases[ph]
-                if n_k:
-                    ach = ab[ph] / (ms_k / n_k * 1e-3) / 1e9
-                    out["kernels"][kern] = {"avg_launch_us": ms_k / n_k * 1e3, "launches": n_k,
-                                            "algorithmic_bytes_per_launch": ab[ph], "achieved_GBs": ach,
-                                            "frac_of_8TBs": ach / HBM_PEAK_GBS,
-                                            "traffic": tr[0].get(ph) if tr else None}
+            out["kernels"] = kernel_table(phases, ab, tr[0] if tr else None, FUSED_NAMES)
+            # the materialised backward sweep against HBM: SURVEY 8(d)'s contract figure (dense tensors in HBM)
+            ab_m = mat["ab"]
+            ms, n = mat["phases"]["backward"]
+            avg_s = ms / max(n, 1) * 1e-3
+            achieved = ab_m["backward"] / avg_s / 1e9
+            roof_m = {"bound": "hbm", "kernel": "backward Riccati sweep over the materialised expansion (backward_tile16_kernel)",
+                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                      "traffic": tr[0].get("backward") if tr else None, "traffic_source": tr[1] if tr else None,
+                      "algorithmic_bytes_per_launch": ab_m["backward"], "avg_launch_us": avg_s * 1e6, "launches": n,
+                      "avg_launch_us_back_to_back": mat["bwd_us_back_to_back"],
+                      "frac_of_measured_copy_peak_6.29TBs": achieved / 6290.0}
+            if args.materialised:
+                out["roofline"] = roof_m
+            else:
+                # The fused kernel never materialises the expansion: its HBM bytes are the trajectory and the gains
+                # ("a fused variant must report against its own smaller byte count and say so"), and what
+                # bounds it is vector-instruction issue: every SIMD of the chip holds one sweep wave and two producer
+                # waves, a wave64 instruction occupies its SIMD for 4 cycles.
+                ms_f, n_f = phases["fused"]
+                avg_f = ms_f / max(n_f, 1) * 1e-3
+                vi = pmc_valu(args.dtype, B, N)
+                insts = vi[0].get("backward_fused16_kernel") if vi else None
+                peak_gips = 1024 * 2.4 / 4.0      # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+                ach = insts / avg_f / 1e9 if insts else None
+                out["roofline"] = {
+                    "bound": "valu", "kernel": "backward_fused16_kernel (acceptance step + linearise + backward sweep; "
+                                               "no expansion in HBM)",
+                    "achieved": ach, "peak": peak_gips, "unit": "G wave-instructions/s",
+                    "frac": ach / peak_gips if ach else None,
+                    "instructions_per_launch": insts, "instructions_source": vi[1] if vi else None,
+                    "traffic": tr[0].get("fused") if tr else None, "traffic_source": tr[1] if tr else None,
+                    "algorithmic_bytes_per_launch": ab["fused"], "avg_launch_us": avg_f * 1e6, "launches": n_f,
+                    "hbm_achieved_GBs_on_own_bytes": ab["fused"] / avg_f / 1e9,
+                    "hbm_frac_on_own_bytes": ab["fused"] / avg_f / 1e9 / HBM_PEAK_GBS,
+                    "note": "bound = vector-instruction issue (SQ_INSTS_VALU per launch / launch time against 1024 SIMDs x "
+                            "2.4 GHz / 4 cycles); the HBM fraction on its own (small) byte count is given beside it; the "
+                            "materialised sweep's HBM roofline is `roofline_materialised`"}
+                out["roofline_materialised"] = roof_m
+                out["materialised"] = {
+                    "ms_per_step": mat["wall_s_per_step"] * 1e3, "value": B / mat["wall_s_per_step"],
+                    "phases_us_per_step": {k: 1e3 * v[0] / args.steps for k, v in mat["phases"].items() if v[1]},
+                    "kernels": kernel_table(mat["phases"], ab_m, tr[0] if tr else None, FUSED_NAMES),
+                    "note": "the same K steps with ILQR_FLAG_NO_FUSE, outside the timed region"}
         if os.environ.get("ILQR_CLOCK_PROBE"):
             pr = h.get(_lib.PROBE)
             out["clock_probe"] = {"backward_cycles": int(pr[0]), "backward_GHz": float(pr[0]) / max(float(pr[1]), 1) * 0.1,
@@ -346,7 +597,7 @@ def main():
             # reported beside the throughput figure, outside every timed region above: the same batch
             # solved to convergence with the reference's stopping rules (tol, maxiter 50, line-search failure)
             hs = sysm.make_handle(horizon=N, batch=B, n_alpha=args.n_alpha, n_trials=10, tol=p["tol"], maxiter=50,
-                                  device=local_rank, stream=stream)
+                                  device=local_rank, flags=path_flags, stream=stream)
             hs.set_problem(x0, U0)
             hs.solve()                       # warm-up (kernel paging, event creation)
             hs.set_problem(x0, U0)
@@ -360,7 +611,8 @@ def main():
                 "converged": int(np.sum(stw == _lib.TRAJ_CONVERGED)), "linesearch_failed": int(np.sum(stw == _lib.TRAJ_LINESEARCH_FAILED)),
                 "maxiter": int(np.sum(stw == _lib.TRAJ_MAXITER)), "tol": p["tol"]}
             hs.close()
-            out["mpc_c4_shard"] = mpc_c4_extra(ilqr_amd, _lib, problems, np_dt, local_rank, stream)
+            out["mpc_c4_shard"] = mpc_extra(ilqr_amd, _lib, problems, np_dt, local_rank, stream)
+            out["configs"] = config_extras(ilqr_amd, _lib, problems, local_rank, stream)
         print(json.dumps(out))
     if world > 1 or args.exchange:
         dist.barrier(device_ids=[local_rank])

@@ -147,14 +147,25 @@ class ShardedBatch:
             device = torch.cuda.current_device()
         # the handle launches on torch's current stream, so torch events / collectives are ordered with its kernels
         ilqr_kw.setdefault("stream", torch.cuda.current_stream(device).cuda_stream or None)
-        self.solver = iLQR(system_factory(), None, x0[self.lo:self.hi], U_init[self.lo:self.hi],
-                           device=device, verbose=False, **ilqr_kw)
+        self._x0, self._U0 = x0[self.lo:self.hi], U_init[self.lo:self.hi]
+        self.solver = iLQR(system_factory(), None, self._x0, self._U0, device=device, verbose=False, **ilqr_kw)
         self._stats = torch.zeros(4, dtype=torch.float64, device=f"cuda:{device}")
         self._xchg = None
 
     def solve(self):
         X, U, cost = self.solver.optimize_trajectory()
         return X, U, cost
+
+    def mpc_reset(self, keep_state=False):
+        """Start the shard's device-resident controllers at the plant states / warm starts given to the constructor
+        (run_iLQR_UA_MPC.py:146-174 for every instance of the shard; c4 = 8192 instances, 1024 per GPU)."""
+        self.solver.mpc_reset(self._x0, self._U0, keep_state=keep_state)
+
+    def mpc_run(self, n_steps):
+        """n_steps receding-horizon steps of every instance of this rank's shard, device-resident (ilqr_mpc_run).
+        No data crosses GPUs; call global_status() for the all-reduced {min cost, max |dcost|, #active, #converged}.
+        Returns this shard's (U_sim, X_sim, cost) = (n_steps, B_local, n_u), (n_steps, B_local, n_x), (n_steps, B_local)."""
+        return self.solver.mpc_run(n_steps)
 
     def global_status(self) -> GlobalStatus:
         import torch
