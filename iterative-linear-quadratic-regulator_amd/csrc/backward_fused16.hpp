@@ -27,18 +27,23 @@
 
 namespace ilqr {
 
-template <typename T> struct FusedCfg;
-// P: producer waves; RU: ring slots (units of 4 time steps x 16 trajectories); TILE: scalars between two tiles in LDS
-// (48 + padding: the 16-byte writes of 8 neighbouring lanes then fall into distinct banks in fp32 -- 52 dwords; fp64 keeps
-// its tiles 32-byte aligned for the double4 reads of the sweep and takes a two-way conflict on the writes)
-template <> struct FusedCfg<float> { static constexpr int P = 8, RU = 8, TILE = 52; };
-template <> struct FusedCfg<double> { static constexpr int P = 4, RU = 4, TILE = 52; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
-constexpr int kFusedUnitSteps = 4;
+// TPW: trajectories per workgroup = 16 (four sweep waves: the big-batch form, one workgroup per CU at B = 4096) or 4
+// (one sweep wave: a batch of <= 1024 then spreads over all 256 CUs instead of 64, and the kernel's duration falls from
+// the CU's vector-issue bound -- 16 trajectories' worth of linearisation -- to the sweep's own latency chain).
+// P: producer waves; RU: ring slots (units of 64 tiles = 64 / TPW time steps x TPW trajectories); TILE: scalars between
+// two tiles in LDS (48 + padding: the 16-byte writes of 8 neighbouring lanes then fall into distinct banks in fp32 --
+// 52 dwords; fp64 keeps its tiles 32-byte aligned for the double4 reads of the sweep and takes a two-way conflict on
+// the writes)
+template <typename T, int TPW> struct FusedCfg;
+template <> struct FusedCfg<float, 16> { static constexpr int P = 8, RU = 8, TILE = 52; };
+template <> struct FusedCfg<double, 16> { static constexpr int P = 4, RU = 4, TILE = 52; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
+template <> struct FusedCfg<float, 4> { static constexpr int P = 3, RU = 4, TILE = 52; };
+template <> struct FusedCfg<double, 4> { static constexpr int P = 3, RU = 3, TILE = 52; };
 
-template <typename T> constexpr int fused_lds_bytes() {
-    return FusedCfg<T>::RU * kFusedUnitSteps * 16 * FusedCfg<T>::TILE * (int)sizeof(T) + (FusedCfg<T>::RU + 4 + 32 + 4) * 4;
+template <typename T, int TPW> constexpr int fused_lds_bytes() {
+    return FusedCfg<T, TPW>::RU * 64 * FusedCfg<T, TPW>::TILE * (int)sizeof(T) + (FusedCfg<T, TPW>::RU + 4 + 32 + 4) * 4;
 }
-template <typename T> constexpr int fused_threads() { return 256 + 64 * FusedCfg<T>::P; }
+template <typename T, int TPW> constexpr int fused_threads() { return 64 * (TPW / 4 + FusedCfg<T, TPW>::P); }
 
 // the sweep's view of a tile in LDS, and the step that consumes it
 template <typename T> struct FusedStep;
@@ -72,24 +77,28 @@ ILQR_DEV void compiler_fence() { asm volatile("" ::: "memory"); }
 ILQR_DEV int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 ILQR_DEV void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <typename T, typename Dyn, int INTEG>
-__global__ void __launch_bounds__(fused_threads<T>()) backward_fused16_kernel(KArgs<T> a) {
+template <typename T, typename Dyn, int INTEG, int TPW>
+__global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     static_assert(NU == 1 && NX >= 2 && NX <= 4, "the fused sweep serves the n_u = 1 DPP tile");
-    constexpr int P = FusedCfg<T>::P, RU = FusedCfg<T>::RU, TL = FusedCfg<T>::TILE, US = kFusedUnitSteps;
-    constexpr int UNIT = US * 16 * TL;           // scalars per ring slot
+    static_assert(TPW == 16 || TPW == 4, "16 or 4 trajectories per workgroup");
+    using Cfg = FusedCfg<T, TPW>;
+    constexpr int P = Cfg::P, RU = Cfg::RU, TL = Cfg::TILE;
+    constexpr int NSW = TPW / 4;                 // sweep waves
+    constexpr int US = 64 / TPW;                 // time steps per unit (a producer wave = 64 tiles)
+    constexpr int UNIT = 64 * TL;                // scalars per ring slot
     constexpr int R = gain_record(NX, 1);
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
     using V4 = typename Vec4<T>::type;
     extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
     T* ring = reinterpret_cast<T*>(fused_lds);
     int* ready = reinterpret_cast<int*>(fused_lds + (size_t)RU * UNIT * sizeof(T));   // [RU] unit index + 1 held by the slot
-    int* done = ready + RU;                      // [4]  units fully read, per sweep wave
+    int* done = ready + RU;                      // [4]  units fully read, per sweep wave (NSW of them used)
     int* s_slot = done + 4;                      // [16] slot of the trajectory's current (X, U)
     int* s_stat = s_slot + 16;                   // [16] status word after the acceptance step (-1: beyond the batch)
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int b0 = blockIdx.x * 16;
+    const int b0 = blockIdx.x * TPW;
     const size_t B = a.B;
     const int N = a.N;
 
@@ -99,7 +108,7 @@ __global__ void __launch_bounds__(fused_threads<T>()) backward_fused16_kernel(KA
         if (lane < 16) {
             const int b = b0 + lane;
             int slot = 0, st = -1;
-            if (b < a.B) {
+            if (lane < TPW && b < a.B) {
                 if (a.fuse_select) {
                     still = select_candidates(a, b, true, slot, st);
                 } else {
@@ -128,7 +137,7 @@ __global__ void __launch_bounds__(fused_threads<T>()) backward_fused16_kernel(KA
     if (!any) return;     // (uniform over the workgroup)
 
     const int n_units = (N + US - 1) / US;
-    if (wave < 4) {
+    if (wave < NSW) {
         // ================= sweep: 4 trajectories per wave, lane (i, j) of a 16-lane row owns V_xx[i][j] ===============
         __builtin_amdgcn_s_setprio(2);
         const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
@@ -171,46 +180,63 @@ __global__ void __launch_bounds__(fused_threads<T>()) backward_fused16_kernel(KA
         lc.tr_byte = 4 * ((lane & 48) | (j << 2) | i);
         bool all_pd = true;
         using FS = FusedStep<T>;
-        auto tile_ptr = [&](int s) -> const T* {
-            const int k = s / US, r = s % US;
-            return ring + (size_t)(k % RU) * UNIT + (r * 16 + tl) * TL;
-        };
-        auto wait_ready = [&](int k) {
-            while (lds_peek(&ready[k % RU]) < k + 1) __builtin_amdgcn_s_sleep(1);
-            compiler_fence();
-        };
-        typename FS::Tile cur, nxt;
-        wait_ready(0);
-        FS::load(cur, tile_ptr(0), i, j, l16);
-        nxt = cur;
         int goff = (N - 1) * rstride;
-        for (int s0 = 0; s0 < N; s0 += US) {
+        // this trajectory's tile of time step r of unit k sits at unit_base(k) + r * TPW * TL: a compile-time offset per step
+        auto unit_base = [&](int k) -> const T* { return ring + (size_t)(k % RU) * UNIT + tl * TL; };
+        auto one_step = [&](const typename FS::Tile& c) {
+            T Kj, kff;
+            bool pd;
+            FS::step(c, lc, V, vx, Kj, kff, pd);
+            all_pd = all_pd && pd;
+            if (DROP || storer) buf_store1(rgain, rec_off, uniform(goff), (i == 0) ? Kj : kff);
+            goff -= rstride;
+        };
+        // Two tile buffers used alternately (US is even, so the buffer of a step is a compile-time choice: no copies);
+        // the tile of step s + 1 is read from LDS while step s computes.  The flag of the next unit is fetched one step
+        // before it is needed, so its LDS round trip is not exposed either.
+        typename FS::Tile tq[2];
+        while (lds_peek(&ready[0]) < 1) __builtin_amdgcn_s_sleep(1);
+        compiler_fence();
+        FS::load(tq[0], unit_base(0), i, j, l16);
+        const int n_full = N / US, rem = N % US;
+        for (int k = 0; k < n_full; ++k) {
+            const T* ub = unit_base(k);
+            const bool more = (k + 1) * US < N;
+            int flag = 0;
 #pragma unroll
             for (int r = 0; r < US; ++r) {
-                const int s = s0 + r;
-                if (s < N) {
-                    if (s + 1 < N) {
-                        if (r == US - 1) wait_ready((s + 1) / US);
-                        FS::load(nxt, tile_ptr(s + 1), i, j, l16);
+                if (r == US - 2 && more) flag = lds_peek(&ready[(k + 1) % RU]);
+                if (r < US - 1) {
+                    FS::load(tq[(r + 1) & 1], ub + (r + 1) * TPW * TL, i, j, l16);
+                } else if (more) {
+                    while (flag < k + 2) {
+                        __builtin_amdgcn_s_sleep(1);
+                        flag = lds_peek(&ready[(k + 1) % RU]);
                     }
-                    T Kj, kff;
-                    bool pd;
-                    FS::step(cur, lc, V, vx, Kj, kff, pd);
-                    all_pd = all_pd && pd;
-                    if (DROP || storer) buf_store1(rgain, rec_off, uniform(goff), (i == 0) ? Kj : kff);
-                    goff -= rstride;
-                    cur = nxt;
+                    compiler_fence();
+                    FS::load(tq[0], unit_base(k + 1), i, j, l16);
                 }
+                one_step(tq[r & 1]);
             }
             // every read of this unit has been issued (LDS serves a wave in order): its ring slot may be overwritten
             compiler_fence();
-            if (lane == 0) lds_poke(&done[wave], s0 / US + 1);
+            if (lane == 0) lds_poke(&done[wave], k + 1);
+        }
+        if (rem) {      // the last, partial unit (its first tile is in tq[0] already)
+            const T* ub = unit_base(n_full);
+#pragma unroll
+            for (int r = 0; r < US - 1; ++r) {
+                if (r < rem) {
+                    if (r + 1 < rem) FS::load(tq[(r + 1) & 1], ub + (r + 1) * TPW * TL, i, j, l16);
+                    one_step(tq[r & 1]);
+                }
+            }
         }
         if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
     } else {
         // ================= producers: lane = (trajectory tl, time step r of the unit) ================================
-        const int pw = wave - 4;
-        const int tl = lane & 15, r = lane >> 4;
+        const int pw = wave - NSW;
+        const int tl = lane % TPW, r = lane / TPW;
         const int gidx = b0 + tl;
         const bool valid = gidx < a.B;
         const int b = valid ? gidx : a.B - 1;
@@ -238,15 +264,20 @@ __global__ void __launch_bounds__(fused_threads<T>()) backward_fused16_kernel(KA
             // the ring slot is free once every sweep wave has read unit k - RU
             if (k >= RU) {
                 const int need = k - RU + 1;
-                while (min(min(lds_peek(&done[0]), lds_peek(&done[1])), min(lds_peek(&done[2]), lds_peek(&done[3]))) < need)
-                    __builtin_amdgcn_s_sleep(2);
+                auto slowest = [&]() {
+                    int m = lds_peek(&done[0]);
+#pragma unroll
+                    for (int q = 1; q < NSW; ++q) m = min(m, lds_peek(&done[q]));
+                    return m;
+                };
+                while (slowest() < need) __builtin_amdgcn_s_sleep(2);
             }
             compiler_fence();
             if (inr) {
                 constexpr int NQ = 12 * (int)sizeof(V4) / 16;       // 16-byte pieces of the tile
                 vec_u4 w[NQ];
                 __builtin_memcpy(w, tile, sizeof(V4) * 12);
-                vec_u4* dst = reinterpret_cast<vec_u4*>(ring + (size_t)(k % RU) * UNIT + (r * 16 + tl) * TL);
+                vec_u4* dst = reinterpret_cast<vec_u4*>(ring + (size_t)(k % RU) * UNIT + (r * TPW + tl) * TL);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) dst[q] = w[q];
             }

@@ -135,16 +135,27 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
     };
     if constexpr (TILE && Dyn::NU == 1 && ((ILQR_FUSE_INTEG_MASK >> I) & 1)) {
         o.fused[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
-            // one workgroup = 16 trajectories: 4 sweep waves + the producer waves, tiles through ~104 KB of LDS
+            // one workgroup = 16 trajectories (4 sweep waves + the producer waves, tiles through ~104 KB of LDS: one per
+            // CU), or 4 trajectories (1 sweep wave, ~52 KB) while the batch then still fits the chip one workgroup per CU
+            // (measured, fp32 fused kernel: B = 1024 35 vs 41 us, B = 2048 41 vs 41, B = 4096 73 vs 47)
             static const bool ok = [] {
-                const bool r = hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T>()) == hipSuccess;
+                bool r = hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 16>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16>()) == hipSuccess;
+                r = r && hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 4>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4>()) == hipSuccess;
                 (void)hipGetLastError();
                 return r;
             }();
             (void)ok;
-            ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I>), dim3((a.B + 15) / 16), dim3(fused_threads<T>()),
-                        fused_lds_bytes<T>(), s, a);
+            static const int force = getenv("ILQR_FUSED_TPW") ? atoi(getenv("ILQR_FUSED_TPW")) : 0;   // A/B switch
+            static const int small_max = getenv("ILQR_FUSED_SMALL_MAX") ? atoi(getenv("ILQR_FUSED_SMALL_MAX")) : 1024;
+            const bool small = force ? force == 4 : a.B <= small_max;
+            if (small)
+                ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 4>), dim3((a.B + 3) / 4), dim3(fused_threads<T, 4>()),
+                            (fused_lds_bytes<T, 4>()), s, a);
+            else
+                ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16>()),
+                            (fused_lds_bytes<T, 16>()), s, a);
         };
     }
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {

@@ -8,10 +8,12 @@ from ilqr_amd import _lib, problems
 
 p = problems.ua_double_pendulum()
 dts = [np.float32, np.float64] if "--f64" in sys.argv else [np.float32]
+Bs = [int(v) for v in os.environ.get("FUSED_AB_B", "4096,1024,256").split(",")]
+paths = (("fused", 0),) if "--fused-only" in sys.argv else (("fused", 0), ("materialised", _lib.FLAG_NO_FUSE))
 for dt in dts:
-    for B in (4096, 1024, 256):
+    for B in Bs:
         x0, U0 = problems.ua_batch(B, seed=0)
-        for tag, fl in (("fused", 0), ("materialised", _lib.FLAG_NO_FUSE)):
+        for tag, fl in paths:
             h = ilqr_amd.make_system(p["dynamics"], p["cost"], dt).make_handle(
                 horizon=200, batch=B, n_alpha=10, maxiter=1 << 30, flags=_lib.FLAG_KEEP_ITERATING | fl)
             h.set_problem(x0, U0); h.initial_rollout(); h.iterate(5); h.sync()
