@@ -66,6 +66,12 @@ SolverBase* make_solver_f64(const ilqr_config& cfg, std::string& err, int* statu
 bool supported_f32(int system, int n_x, int n_u);
 bool supported_f64(int system, int n_x, int n_u);
 
+// Largest tensor the kernels address through a 32-bit buffer descriptor.  Dead lanes' stores are dropped by giving them
+// the byte offset 0x7ffffff0 (kernels.hpp, backward_tile16.hpp, backward_fused16.hpp), which the hardware compares with
+// the descriptor's num_records = the tensor's size: a tensor of more than 0x7ffffff0 bytes would turn a dropped store
+// into a landed one, so that -- not 2^31 -- is the bound (tests/test_limits_gpu.py runs at it).
+constexpr size_t kDescriptorMax = 0x7ffffff0ull;
+
 #define ILQR_HIPCHK(expr)                                                                      \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -166,7 +172,7 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             // (X is the largest state tensor, U <= X; the gain tensor can be larger than X when n_alpha is small)
             const size_t bytes_x = (size_t)a.n_slots * (a.N + 1) * Dyn::NX * a.B * sizeof(T);
             const size_t bytes_g = (size_t)a.N * a.B * gain_record(Dyn::NX, Dyn::NU) * sizeof(T);
-            const bool fits = std::max(bytes_x, bytes_g) < (1ull << 31);
+            const bool fits = std::max(bytes_x, bytes_g) <= kDescriptorMax;
             if (fits && !plain) {
                 ILQR_LAUNCH((forward_ring_kernel<T, Dyn, I>), grid, block, 0, s, a);
                 return;
@@ -213,8 +219,8 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
             static const bool lds_ring = getenv("ILQR_BACKWARD_LDS_RING") != nullptr;  // A/B switch for profiling
             // the register-ring kernel addresses both tensors through 32-bit buffer offsets
             // (the gain tensor, gain_record(NX, 1) <= 8 scalars per (t, b), is always the smaller of the two)
-            const bool fits = (size_t)a.N * a.B * kTile16 * sizeof(T) < (1ull << 31) &&
-                              (size_t)a.N * a.B * gain_record(NX, 1) * sizeof(T) < (1ull << 31);
+            const bool fits = (size_t)a.N * a.B * kTile16 * sizeof(T) <= kDescriptorMax &&
+                              (size_t)a.N * a.B * gain_record(NX, 1) * sizeof(T) <= kDescriptorMax;
             if (lds_ring || !fits) {
                 const dim3 grid((a.B + 3) / 4), block(64);
                 if (a.mu != T(0)) ILQR_LAUNCH((backward_tile16_lds_kernel<T, true, NX>), grid, block, 0, s, a);
@@ -280,7 +286,7 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
                 static const bool wave = getenv("ILQR_FORWARD_WAVE") != nullptr;   // A/B: wave per (trajectory, alpha)
                 const size_t bytes_x = (size_t)a.n_slots * (a.N + 1) * NX * a.B * sizeof(T);
                 const size_t bytes_g = (size_t)a.N * a.B * gain_record(NX, NU) * sizeof(T);
-                if (!wave && a.n_pass <= 16 && std::max(bytes_x, bytes_g) < (1ull << 31)) {
+                if (!wave && a.n_pass <= 16 && std::max(bytes_x, bytes_g) <= kDescriptorMax) {
                     ILQR_LAUNCH((forward_mfma16_kernel<T>), dim3(a.B), dim3(64), 0, s, a);
                     return;
                 }
@@ -514,7 +520,7 @@ template <typename T> class SolverT : public SolverBase {
             err = "no kernels compiled for this (system, n_x, n_u, dtype)";
             return ILQR_ERR_UNSUPPORTED;
         }
-        if (ops.tile_scalars == kTile16M2 && (size_t)N * B * kTile16M2 * sizeof(T) >= (1ull << 31)) {
+        if (ops.tile_scalars == kTile16M2 && (size_t)N * B * kTile16M2 * sizeof(T) > kDescriptorMax) {
             err = "n_x = 4, n_u = 2: horizon * batch too large for the sweep's 32-bit tile offsets (< 2 GiB of tiles)";
             return ILQR_ERR_UNSUPPORTED;
         }
@@ -855,7 +861,7 @@ template <typename T> class SolverT : public SolverBase {
     bool fused_ok() const {
         static const bool off = getenv("ILQR_NO_FUSE") != nullptr;   // A/B switch, and bench.py's materialised leg
         return !off && !force_unfused && !(cfg.flags & ILQR_FLAG_NO_FUSE) && ops.fused[cfg.integrator] && cfg.mu == 0.0 && (int)trial_alphas.size() <= A &&
-               (size_t)N * B * R * sizeof(T) < 0x7ffffff0ull;
+               (size_t)N * B * R * sizeof(T) <= kDescriptorMax;
     }
     bool force_unfused = false;
     int flush_select() {
