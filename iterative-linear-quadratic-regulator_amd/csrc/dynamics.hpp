@@ -36,7 +36,9 @@ template <> struct M<float> {
     static ILQR_DEV float abs(float x) { return fabsf(x); }
     static constexpr float kMagic = 12582912.0f;             // 1.5 * 2^23: x/pi + kMagic rounds to nearest int
     static constexpr float kInvPi = 0x1.45f306p-2f;
-    static constexpr float kPiHi = 0x1.921fb6p+1f, kPiMid = -0x1.777a5cp-24f, kPiLo = -0x1.ee59dap-49f;
+    // pi = kPiHi + kPiMid - 3.4e-15: the third Cody-Waite term would move r by n * 3.4e-15 <= 1e-12 for |x| < 1e3, five
+    // orders below an fp32 ulp of r, so two terms are all the reduction takes
+    static constexpr float kPiHi = 0x1.921fb6p+1f, kPiMid = -0x1.777a5cp-24f;
     static constexpr float kS0 = -0x1.555548p-3f, kS1 = 0x1.110e42p-7f, kS2 = -0x1.9f588ap-13f, kS3 = 0x1.5c90a2p-19f;
     static constexpr float kC0 = -0.5f, kC1 = 0x1.555546p-5f, kC2 = -0x1.6c134cp-10f, kC3 = 0x1.9f68bp-16f,
                            kC4 = -0x1.17b08ap-22f;
@@ -45,7 +47,6 @@ template <> struct M<float> {
         const float n = t - kMagic;
         float r = fmaf(-n, kPiHi, x);
         r = fmaf(-n, kPiMid, r);
-        r = fmaf(-n, kPiLo, r);
         const float z = r * r;
         const float ps = fmaf(fmaf(fmaf(kS3, z, kS2), z, kS1), z, kS0);
         const float s = fmaf(r * z, ps, r);
@@ -57,13 +58,12 @@ template <> struct M<float> {
     }
     static ILQR_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
     static ILQR_DEV f2 splat(float v) { f2 r; r.x = v; r.y = v; return r; }
-    static ILQR_DEV void sincos2(float x0, float x1, float* s0, float* c0, float* s1, float* c1) {
-        f2 x; x.x = x0; x.y = x1;
+    // sin / cos of a pair of angles in packed FP32: exactly the arithmetic of sincos() on each half
+    static ILQR_DEV void sincos_pk(f2 x, f2* sn, f2* cs) {
         const f2 t = fma2(x, splat(kInvPi), splat(kMagic));
         const f2 n = t - splat(kMagic);
         f2 r = fma2(-n, splat(kPiHi), x);
         r = fma2(-n, splat(kPiMid), r);
-        r = fma2(-n, splat(kPiLo), r);
         const f2 z = r * r;
         const f2 ps = fma2(fma2(fma2(splat(kS3), z, splat(kS2)), z, splat(kS1)), z, splat(kS0));
         const f2 s = fma2(r * z, ps, r);
@@ -74,7 +74,13 @@ template <> struct M<float> {
         f2 sg;
         sg.x = __uint_as_float((__float_as_uint(t.x) << 31) | 0x3f800000u);
         sg.y = __uint_as_float((__float_as_uint(t.y) << 31) | 0x3f800000u);
-        const f2 ss = s * sg, cc = c * sg;
+        *sn = s * sg;
+        *cs = c * sg;
+    }
+    static ILQR_DEV void sincos2(float x0, float x1, float* s0, float* c0, float* s1, float* c1) {
+        f2 x; x.x = x0; x.y = x1;
+        f2 ss, cc;
+        sincos_pk(x, &ss, &cc);
         *s0 = ss.x; *c0 = cc.x; *s1 = ss.y; *c1 = cc.y;
     }
 };
@@ -212,6 +218,53 @@ template <typename T, int NU_> struct DoublePendulum {
         xd[1] = q2d;
         xd[2] = (m22 * h1 - m12 * h2) * idet;
         xd[3] = (m11 * h2 - m12 * h1) * idet;
+    }
+
+    // ---- the fp32 rollout's RK4 step on PAIRS: Q = (q1, q2), W = (q1', q2') in packed FP32 (v_pk_fma_f32 issues at the
+    // rate of v_fma_f32, tools/micro/pk_rate.hip, and the rollout is bound by its instruction count).  The same formulas
+    // as f() above with the two generalised forces, the two rows of the 2 x 2 solve and the RK4 combinations each as
+    // ONE packed operation; (m22, m11) is built as a pair so the solve needs no register shuffles.  Differences to f()
+    // are association only: w = (2 q1' + q2') q2' for 2 q1' q2' + q2'^2, and (a s2 / 2) q1'^2 for ((a s2 / 2) q1') q1'.
+    static constexpr bool RK4_PK = true;
+    typedef float pf2 __attribute__((ext_vector_type(2)));
+    static ILQR_DEV pf2 pk_fma(pf2 a, pf2 b, pf2 c) { return __builtin_elementwise_fma(a, b, c); }
+    static ILQR_DEV pf2 pk_splat(float v) { pf2 r; r.x = v; r.y = v; return r; }
+    static ILQR_DEV pf2 acc_pk(const float* __restrict__ p, pf2 Q, pf2 W, pf2 uu) {
+        const float a = p[0], c11 = p[1], c12 = p[2], gA = p[3], gB = p[4], d1 = p[5], d2 = p[6];
+        pf2 S, C;
+        M<float>::sincos_pk(Q, &S, &C);                            // (s1, s2), (c1, c2)
+        const float s12 = fmaf(C.x, S.y, S.x * C.y);               // sin(q1 + q2)
+        pf2 cm; cm.x = c12; cm.y = c11;
+        pf2 am; am.x = 0.0f; am.y = a;
+        const pf2 Mx = pk_fma(am, pk_splat(C.y), cm);              // (m22, m11)
+        const float m12 = fmaf(0.5f * a, C.y, c12);
+        const float as2h = (0.5f * a) * S.y;
+        pf2 t; t.x = fmaf(2.0f, W.x, W.y); t.y = -W.x;
+        const pf2 wv = t * W.yx;                                   // (w, -q1'^2)
+        pf2 H = pk_fma(pk_splat(as2h), wv, uu);                    // (u1 + a s2 w / 2, u2 - a s2 q1'^2 / 2)
+        H = pk_fma(pk_splat(-gA), pk_splat(s12), H);
+        H.x = fmaf(-gB, S.x, H.x);
+        pf2 dd; dd.x = d1; dd.y = d2;
+        H = pk_fma(-dd, W, H);                                     // (h1, h2)
+        const float idet = fast_rcp(fmaf(Mx.y, c12, -(m12 * m12)));
+        const pf2 num = pk_fma(Mx, H, -(pk_splat(m12) * H.yx));    // (m22 h1 - m12 h2, m11 h2 - m12 h1)
+        return num * pk_splat(idet);
+    }
+    static ILQR_DEV void rk4_pk(const float* __restrict__ p, float dt, const float* x, const float* u, float* xn) {
+        pf2 Q, W, uu;
+        Q.x = x[0]; Q.y = x[1]; W.x = x[2]; W.y = x[3];
+        uu.x = u[0]; uu.y = (NU == 2) ? u[NU - 1] : 0.0f;
+        const pf2 hh = pk_splat(dt / 2.0f), h = pk_splat(dt), h6 = pk_splat(dt / 6.0f), two = pk_splat(2.0f);
+        const pf2 A1 = acc_pk(p, Q, W, uu);
+        const pf2 W2 = pk_fma(hh, A1, W);
+        const pf2 A2 = acc_pk(p, pk_fma(hh, W, Q), W2, uu);
+        const pf2 W3 = pk_fma(hh, A2, W);
+        const pf2 A3 = acc_pk(p, pk_fma(hh, W2, Q), W3, uu);
+        const pf2 W4 = pk_fma(h, A3, W);
+        const pf2 A4 = acc_pk(p, pk_fma(h, W3, Q), W4, uu);
+        const pf2 Qn = pk_fma(h6, pk_fma(two, W3, pk_fma(two, W2, W)) + W4, Q);
+        const pf2 Wn = pk_fma(h6, pk_fma(two, A3, pk_fma(two, A2, A1)) + A4, W);
+        xn[0] = Qn.x; xn[1] = Qn.y; xn[2] = Wn.x; xn[3] = Wn.y;
     }
 
     // M qdd = h  =>  d qdd = M^-1 (dh - dM qdd)
@@ -358,6 +411,12 @@ template <typename Dyn> struct second_order<Dyn, decltype((void)Dyn::SECOND_ORDE
     static constexpr bool value = Dyn::SECOND_ORDER && Dyn::NX % 2 == 0;
 };
 
+// a Dyn with RK4_PK offers the fp32 rollout a hand-packed RK4 step (Dyn::rk4_pk)
+template <typename T, typename Dyn, typename = void> struct rk4_packed { static constexpr bool value = false; };
+#ifndef ILQR_NO_RK4_PK
+template <typename Dyn> struct rk4_packed<float, Dyn, decltype((void)Dyn::RK4_PK)> { static constexpr bool value = Dyn::RK4_PK; };
+#endif
+
 template <typename T, typename Dyn> struct Stepper {
     static constexpr int NX = Dyn::NX, NU = Dyn::NU;
     static constexpr bool SMALL = all_integrators<Dyn>::value;
@@ -419,6 +478,10 @@ template <typename T, typename Dyn> struct Stepper {
                 return;
             }
             if (integ == ILQR_INT_RK4) {
+                if constexpr (rk4_packed<T, Dyn>::value) {
+                    Dyn::rk4_pk(p, dt, x, u, xn);
+                    return;
+                }
                 T xs[NX], k2[NX], k3[NX], k4[NX];
                 Dyn::f(p, x, u, k1);
 #pragma unroll
@@ -616,11 +679,44 @@ template <typename T, typename Dyn> struct Cost {
     static constexpr int NX = Dyn::NX, NU = Dyn::NU;
     static constexpr bool CUSTOM = has_custom_cost<Dyn>::value;
     using L = ParamLayout<Dyn::NSYS, NX, NU>;
+#ifdef ILQR_NO_COST_PK
+    static constexpr bool stage_cost_packed = false;
+#else
+    static constexpr bool stage_cost_packed = true;
+#endif
 
     // l(x,u) = (0.5 dx'Q dx + 0.5 u'R u) * dt
     static ILQR_DEV T stage(const T* __restrict__ p, T dt, const T* x, const T* u) {
         if constexpr (CUSTOM) {
             return Dyn::l(x, u);
+        } else if constexpr (sizeof(T) == 4 && NX == 4 && stage_cost_packed) {
+            // fp32, n_x = 4 (the rollout's hot case): dx'Q dx as (Q'dx)'dx with the two halves of Q'dx accumulated in
+            // packed FP32 -- row i of Q contributes (Q_i0, Q_i1) dx_i and (Q_i2, Q_i3) dx_i, adjacent in the row-major
+            // block -- 11 vector instructions instead of 24; the sum is the same up to the order of its 16 terms.
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto pair = [](float a, float b) { f2 r; r.x = a; r.y = b; return r; };
+            auto bc = [](float a) { f2 r; r.x = a; r.y = a; return r; };
+            const f2 d01 = pair(x[0], x[1]) - pair(p[L::XT + 0], p[L::XT + 1]);
+            const f2 d23 = pair(x[2], x[3]) - pair(p[L::XT + 2], p[L::XT + 3]);
+            f2 r01 = pair(p[L::Q + 0], p[L::Q + 1]) * bc(d01.x);
+            f2 r23 = pair(p[L::Q + 2], p[L::Q + 3]) * bc(d01.x);
+            r01 = __builtin_elementwise_fma(pair(p[L::Q + 4], p[L::Q + 5]), bc(d01.y), r01);
+            r23 = __builtin_elementwise_fma(pair(p[L::Q + 6], p[L::Q + 7]), bc(d01.y), r23);
+            r01 = __builtin_elementwise_fma(pair(p[L::Q + 8], p[L::Q + 9]), bc(d23.x), r01);
+            r23 = __builtin_elementwise_fma(pair(p[L::Q + 10], p[L::Q + 11]), bc(d23.x), r23);
+            r01 = __builtin_elementwise_fma(pair(p[L::Q + 12], p[L::Q + 13]), bc(d23.y), r01);
+            r23 = __builtin_elementwise_fma(pair(p[L::Q + 14], p[L::Q + 15]), bc(d23.y), r23);
+            const f2 cc = __builtin_elementwise_fma(r23, d23, r01 * d01);
+            const T cx = cc.x + cc.y;
+            T cu = T(0);
+#pragma unroll
+            for (int i = 0; i < NU; ++i) {
+                T r = T(0);
+#pragma unroll
+                for (int j = 0; j < NU; ++j) r += p[L::R + i * NU + j] * u[j];
+                cu += u[i] * r;
+            }
+            return (T(0.5) * cx + T(0.5) * cu) * dt;
         } else {
             T dx[NX];
 #pragma unroll

@@ -781,6 +781,21 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     auto do_step = [&](const In& in, int t) {
         T xo[NX], uo[NU], dx[NX];
         in.unpack(xo, uo);
+#ifndef ILQR_NO_CTRL_PK
+        if constexpr (sizeof(T) == 4 && NX == 4) {
+            // fp32, n_x = 4: the feedback K (x - x_old) on pairs in packed FP32 (the same four products, summed pairwise)
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            auto pair = [](float a, float b) { f2 r; r.x = a; r.y = b; return r; };
+            const f2 d01 = pair(x[0], x[1]) - pair(xo[0], xo[1]), d23 = pair(x[2], x[3]) - pair(xo[2], xo[3]);
+#pragma unroll
+            for (int j = 0; j < NU; ++j) {
+                const f2 f = __builtin_elementwise_fma(pair(in.gain(j * NX + 2), in.gain(j * NX + 3)), d23,
+                                                       pair(in.gain(j * NX + 0), in.gain(j * NX + 1)) * d01);
+                u[j] = uo[j] + alpha * in.gain(NU * NX + j) + (f.x + f.y);   // iLQR_class.py:181-182
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int i = 0; i < NX; ++i) dx[i] = x[i] - xo[i];
 #pragma unroll
@@ -789,6 +804,7 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) fb += in.gain(j * NX + i) * dx[i];
             u[j] = uo[j] + alpha * in.gain(NU * NX + j) + fb;   // iLQR_class.py:181-182
+        }
         }
         // exactly NST stores per step for every wave that is still running (they are counted)
         if (DROP || live) {

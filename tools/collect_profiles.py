@@ -34,7 +34,7 @@ for dt in ("f32", "f64"):
                    "(HBM section) FETCH_SIZE on gfx950 reports exactly half of a wide coalesced streaming read, so "
                    "read bytes = 2 * FETCH_SIZE * 1024.",
            "dtype": dt, "batch": 4096, "horizon": 200, "kernels": {}}
-    for kern in ("backward_tile16_kernel", "linearize_kernel", "forward_ring_kernel"):
+    for kern in ("backward_fused16_kernel", "backward_tile16_kernel", "linearize_kernel", "forward_ring_kernel"):
         f, nf = mean_counter(fetch[0], kern)
         w, nw = mean_counter(write[0], kern)
         out["kernels"][kern] = {"FETCH_SIZE_KiB_mean": f, "WRITE_SIZE_KiB_mean": w, "launches": nf,
@@ -42,6 +42,19 @@ for dt in ("f32", "f64"):
                                 "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024}
     json.dump(out, open(os.path.join(dst, f"pmc_traffic_{dt}.json"), "w"), indent=1)
     print(dt, {k: round(v["hbm_bytes_per_launch"] / 1e6, 1) for k, v in out["kernels"].items()}, "MB per launch")
+    valu = newest(f"{src}/pmc_valu_{dt}/*/*_counter_collection.csv")
+    if valu:
+        shutil.copy(valu[0], os.path.join(dst, f"rocprofv3_pmc_SQ_INSTS_VALU_{dt}.csv"))
+        vo = {"note": "rocprofv3 --pmc SQ_INSTS_VALU pass (its own run, --kernel-trace only) of `python bench.py --no-cpu-baseline "
+                      f"--no-solve-extra --steps 5 --dtype {dt}` (B=4096, N=200): vector-ALU instructions issued per launch, summed "
+                      "over all waves of the launch (a wave64 instruction counts once).",
+              "dtype": dt, "batch": 4096, "horizon": 200, "kernels": {}}
+        for kern in ("backward_fused16_kernel", "backward_tile16_kernel", "linearize_kernel", "forward_ring_kernel"):
+            v, nv = mean_counter(valu[0], kern)
+            if nv:
+                vo["kernels"][kern] = {"SQ_INSTS_VALU_per_launch": v, "launches": nv}
+        json.dump(vo, open(os.path.join(dst, f"pmc_valu_{dt}.json"), "w"), indent=1)
+        print(dt, "VALU instructions per launch", {k: round(v["SQ_INSTS_VALU_per_launch"] / 1e6, 2) for k, v in vo["kernels"].items()}, "M")
 # the c5 shard (n=16, m=8, N=500, B=128) and the c4 MPC shard (1024 instances): stats + traffic of every kernel seen
 for w, what in (("c5", "tools/pmc_target_c5.py (c5 shard: n=16 m=8 N=500 B=128 f32, 4 iterations)"),
                 ("mpc", "tools/pmc_target_mpc.py (c4 shard: 1024 MPC instances, N=200, 2 cold + 6 warm steps, f32)")):

@@ -16,7 +16,10 @@ step "c3 $dt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$dt -- python3 $R/bench.py --no-cpu-baseline --no-solve-extra --dtype $dt > $OUT/trace_$dt.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$dt -- python3 $R/bench.py --no-cpu-baseline --no-solve-extra --steps 5 --dtype $dt > $OUT/pmc_fetch_$dt.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$dt -- python3 $R/bench.py --no-cpu-baseline --no-solve-extra --steps 5 --dtype $dt > $OUT/pmc_write_$dt.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d $OUT/pmc_valu_$dt -- python3 $R/bench.py --no-cpu-baseline --no-solve-extra --steps 5 --dtype $dt > $OUT/pmc_valu_$dt.log 2>&1 || exit 1
 done
+# (bench.py runs the fused iteration in its timed region and the materialised one -- linearize_kernel, backward_tile16_kernel,
+# select_kernel -- beside it in the same process, so the passes above hold the kernels of both paths)
 for w in c5 mpc; do
 step "$w f32"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$w -- python3 $R/tools/pmc_target_$w.py > $OUT/trace_$w.log 2>&1 || exit 1

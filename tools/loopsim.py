@@ -54,6 +54,8 @@ for l in body:
         src |= dst
     need = max([ready.get(r, 0.0) for r in src] + [0.0])
     if need > t:
+        if os.environ.get("LOOPSIM_VERBOSE") and need - t > 3:
+            print(f"  stall {need - t:5.1f} at {l}")
         stall += need - t
         t = need
     dur, lat = (int(ops.strip() or 0) + 1, 0.0) if c == "nop" else COST[c]
