@@ -261,20 +261,46 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
         // issues each product's four dependent instructions back to back (40 cycles of latency each, measured: ~1100 of a
         // step's ~3500 cycles in front of the factorisation); round-robin over independent chains the pipe takes one
         // every 32 cycles.
+        // Round 3: the order follows what the factorisation waits for.  The vector ALU cannot start on Q_uu before
+        // (B'V)' and Q_uu itself are through the pipe, and nothing else is: (B'V)' goes first with (A'V)' filling the
+        // pipe behind it while its result drains, then Q_uu's four instructions; Q_ux (needed by the substitution) and
+        // Q_xx (needed by the value update) are issued last and execute UNDER the factorisation's ~1000 cycles of vector
+        // work instead of in front of it (the matrix pipe runs beside the vector ALU; a lone wave only has to issue them).
 #define ILQR_MFMA_NEXT() __builtin_amdgcn_sched_barrier(0)
+        acc qx_acc, qxx_acc;
         {
-            // (B'V)' and (A'V)', two accumulators each
             acc p0 = zero, p1 = zero, t0 = zero, t1 = zero;
             p0 = MF::mma(V[0], cur.Bm[0], p0); ILQR_MFMA_NEXT();
-            t0 = MF::mma(V[0], cur.A[0], t0); ILQR_MFMA_NEXT();
             p1 = MF::mma(V[1], cur.Bm[1], p1); ILQR_MFMA_NEXT();
-            t1 = MF::mma(V[1], cur.A[1], t1); ILQR_MFMA_NEXT();
             p0 = MF::mma(V[2], cur.Bm[2], p0); ILQR_MFMA_NEXT();
-            t0 = MF::mma(V[2], cur.A[2], t0); ILQR_MFMA_NEXT();
             p1 = MF::mma(V[3], cur.Bm[3], p1); ILQR_MFMA_NEXT();
+            t0 = MF::mma(V[0], cur.A[0], t0); ILQR_MFMA_NEXT();
+            t1 = MF::mma(V[1], cur.A[1], t1); ILQR_MFMA_NEXT();
+            t0 = MF::mma(V[2], cur.A[2], t0); ILQR_MFMA_NEXT();
             t1 = MF::mma(V[3], cur.A[3], t1); ILQR_MFMA_NEXT();
             arr(p0 + p1, Put);
+            ILQR_MFMA_NEXT();
+            // Q_uu (the factorisation waits for it: two accumulators)
+            acc u0 = vec(cur.luu), u1 = zero;
+            u0 = MF::mma(Put[0], cur.Bm[0], u0); ILQR_MFMA_NEXT();
+            u1 = MF::mma(Put[1], cur.Bm[1], u1); ILQR_MFMA_NEXT();
+            u0 = MF::mma(Put[2], cur.Bm[2], u0); ILQR_MFMA_NEXT();
+            u1 = MF::mma(Put[3], cur.Bm[3], u1); ILQR_MFMA_NEXT();
             arr(t0 + t1, Pt);
+            ILQR_MFMA_NEXT();
+            // Q_ux, Q_xx: in the shadow of the factorisation
+            acc x = vec(cur.lux), y2 = vec(cur.lxx);
+            x = MF::mma(Put[0], cur.A[0], x); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[0], cur.A[0], y2); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[1], cur.A[1], x); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[1], cur.A[1], y2); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[2], cur.A[2], x); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[2], cur.A[2], y2); ILQR_MFMA_NEXT();
+            x = MF::mma(Put[3], cur.A[3], x); ILQR_MFMA_NEXT();
+            y2 = MF::mma(Pt[3], cur.A[3], y2); ILQR_MFMA_NEXT();
+            arr(u0 + u1, Quu);
+            qx_acc = x;
+            qxx_acc = y2;
         }
         ILQR_STAMP(0, Put[0]);
         // Q_u = l_u + B'V_x and Q_x = l_x + A'V_x, column-indexed: 4 products per lane, summed over the lane groups
@@ -286,28 +312,9 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
         }
         qu_c = cur.lu + group_sum(qu_c);
         qx_c = cur.lx + group_sum(qx_c);
-        {
-            // Q_uu (the factorisation waits for it: two accumulators), Q_ux, Q_xx round-robin
-            acc u0 = vec(cur.luu), u1 = zero, x = vec(cur.lux), y2 = vec(cur.lxx);
-            u0 = MF::mma(Put[0], cur.Bm[0], u0); ILQR_MFMA_NEXT();
-            x = MF::mma(Put[0], cur.A[0], x); ILQR_MFMA_NEXT();
-            u1 = MF::mma(Put[1], cur.Bm[1], u1); ILQR_MFMA_NEXT();
-            y2 = MF::mma(Pt[0], cur.A[0], y2); ILQR_MFMA_NEXT();
-            u0 = MF::mma(Put[2], cur.Bm[2], u0); ILQR_MFMA_NEXT();
-            x = MF::mma(Put[1], cur.A[1], x); ILQR_MFMA_NEXT();
-            u1 = MF::mma(Put[3], cur.Bm[3], u1); ILQR_MFMA_NEXT();
-            y2 = MF::mma(Pt[1], cur.A[1], y2); ILQR_MFMA_NEXT();
-            x = MF::mma(Put[2], cur.A[2], x); ILQR_MFMA_NEXT();
-            y2 = MF::mma(Pt[2], cur.A[2], y2); ILQR_MFMA_NEXT();
-            x = MF::mma(Put[3], cur.A[3], x); ILQR_MFMA_NEXT();
-            y2 = MF::mma(Pt[3], cur.A[3], y2); ILQR_MFMA_NEXT();
-            arr(u0 + u1, Quu);
-            arr(x, Qux);
-            arr(y2, Qxx);
-        }
 #undef ILQR_MFMA_NEXT
-        ILQR_STAMP(1, Quu[0] + Qux[0]);
-        ILQR_STAMP(2, Qxx[0] + qu_c + qx_c);
+        ILQR_STAMP(1, Quu[0]);
+        ILQR_STAMP(2, qu_c + qx_c);
 
         // ---- gain solve (:109-110) ---------------------------------------------------------------------------------
         // Quu's lower triangle and Q_u to scalars: row i of Quu lives in lane group grp_of(i), register reg_of(i)
@@ -319,6 +326,7 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
             qu[i] = MF::readlane(qu_c, i);
         }
         // this lane's right-hand side: column c of Q_ux (lanes 0..31, both halves solve the same 16 columns) or Q_u
+        arr(qx_acc, Qux);          // (first reader of Q_ux: the right-hand sides)
         T rhs[NU];
         if constexpr (sizeof(T) == 4) {
             // f32: rows 0-3 of column c sit in lane (0, c), rows 4-7 in lane (1, c): one 16-lane swap per register
@@ -442,6 +450,7 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
 
         // ---- V+ = Q_xx + Q_ux' K (:114); two accumulators: the next step's first product waits for it -------------------
         {
+            arr(qxx_acc, Qxx);
             acc d0 = vec(Qxx), d1 = zero;
             d0 = MF::mma(Qux[0], K[0], d0);
             d1 = MF::mma(Qux[1], K[1], d1);
