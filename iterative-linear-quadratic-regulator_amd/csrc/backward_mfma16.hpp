@@ -217,8 +217,18 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) aRow[r] = 4 * MF::row(g, r);       // lane (0, ROW(g, r)): column-indexed -> row-indexed
 
+    // the constant-matrix form's gradients: behind f_x, f_u in the record, or the dense [N][B][24] tensor at the front
+    // of the buffer when the linearisation wrote its sparse form (KArgs::lin_sparse)
+    const bool dense_grad = CONST && a.lin_sparse;
+    const T* __restrict__ gvec = dense_grad ? a.lin + (size_t)b * (NX + NU) : lin + (NX * NX + NX * NU);
+    const size_t gstride = dense_grad ? B * (NX + NU) : tstride;
     Tile16x8<T> cur, nxt;
     tile16x8_load(cur, lin + (size_t)(N - 1) * tstride, off);
+    if constexpr (CONST) {
+        const __amdgpu_buffer_rsrc_t r0 = make_rsrc(gvec + (size_t)(N - 1) * gstride, (NX + NU) * S);
+        cur.lx = buf_load1(r0, off.vLx, 0, T(0));
+        cur.lu = buf_load1(r0, off.vLu, S * NX, T(0));
+    }
     {
         // Every load of the prologue (first tile, terminal value function) is consumed here, before the loop: hipcc's s_waitcnt bookkeeping then enters the
         // loop with nothing pending.  Otherwise the loop header merges "22 loads pending" (from here) with "22 loads and
@@ -243,9 +253,10 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
     for (int t = N - 1; t >= 0; --t) {
         // the next step's expansion does not depend on the carried value function: request it now
         if constexpr (CONST) {
-            const __amdgpu_buffer_rsrc_t rn = tile16x8_rsrc_of(lin + (size_t)(t > 0 ? t - 1 : 0) * tstride);
-            nxt.lx = buf_load1(rn, off.vLx, S * (NX * NX + NX * NU), T(0));
-            nxt.lu = buf_load1(rn, off.vLu, S * (NX * NX + NX * NU + NX), T(0));
+            // l_x, l_u: 24 adjacent scalars, in the record (full form) or in the dense side tensor (sparse form)
+            const __amdgpu_buffer_rsrc_t rn = make_rsrc(gvec + (size_t)(t > 0 ? t - 1 : 0) * gstride, (NX + NU) * S);
+            nxt.lx = buf_load1(rn, off.vLx, 0, T(0));
+            nxt.lu = buf_load1(rn, off.vLu, S * NX, T(0));
         } else {
             tile16x8_load(nxt, lin + (size_t)(t > 0 ? t - 1 : 0) * tstride, off);
         }

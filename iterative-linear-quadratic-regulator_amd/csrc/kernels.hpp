@@ -58,7 +58,9 @@ template <typename T> struct KArgs {
     int const_lin;     // the expansion's matrices are the same at every (t, b) (a Linear system with the built-in quadratic
                        // cost: only l_x, l_u vary); set by the host for the library's own linearisation, never for caller tensors
     int fuse_select;   // backward_fused16_kernel: run the acceptance step of the previous iteration's candidates first
-    int lin_sparse;    // linearize_wave_kernel: write the constant matrices at t = N-1 only (what the CONST sweep reads), l_x, l_u everywhere
+    int lin_sparse;    // the expansion of a constant-matrix system in its sparse form: the matrices in the records of t = N-1 only
+                       // (what the CONST sweep reads), l_x, l_u of every (t, b) as a dense [N][B][n_x + n_u] tensor at the front of `lin`
+    int t_first;       // linearize_wave_kernel: first time step of the launch (0, or N-1 for the sparse form)
     const T* params;
     long long* probe;  // diagnostic: {shader cycles, 100 MHz ticks} of block 0 per kernel, or nullptr
 };
@@ -1082,19 +1084,47 @@ template <typename T> struct MpcArgs {
     T* u_log; T* x_log; T* cost_log; const T* cost;  // logs in the ABI layout [n_steps][B][...], or NULL
 };
 
+// Workgroup = 64 trajectories x kMpcChunks slices of the horizon (threadIdx.y): the shift U[t] <- U[t + 1] reads its
+// slice into registers, the workgroup synchronises, then writes -- a lane no longer walks its whole column alone (200
+// dependent load / store pairs: 66 us of the c4 step, now a few).  Slice 0 also runs the plant step.  Horizons beyond
+// kMpcChunks * (32 / n_u) + 1 steps fall back to the walk.
+constexpr int kMpcChunks = 16, kMpcSliceScalars = 32;   // a slice keeps at most 32 scalars per lane in registers
 template <typename T, typename Dyn>
-__global__ void __launch_bounds__(64) mpc_advance_kernel(MpcArgs<T> a) {
+__global__ void __launch_bounds__(64 * kMpcChunks) mpc_advance_kernel(MpcArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= a.B) return;
+    constexpr int kMpcSlice = kMpcSliceScalars / NU > 0 ? kMpcSliceScalars / NU : 1;
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    const int chunk = threadIdx.y;
     const size_t B = a.B;
-    T* Uc = a.U + vec_at(B, a.N, NU, a.cur_slot[b], 0, b);
+    const bool inb = b < a.B;
+    const int bb = inb ? b : a.B - 1;
+    T* Uc = a.U + vec_at(B, a.N, NU, a.cur_slot[bb], 0, bb);
     const size_t sU = B * NU;
-    T x[NX], u[NU], xn[NX];
+    const int n_shift = a.N - 1;                                   // U[t] <- U[t + 1], t = 0 .. N-2
+    const int per = (n_shift + kMpcChunks - 1) / kMpcChunks;       // time steps per slice
+    const bool sliced = per <= kMpcSlice;
+    T u0[NU];
+    vec_load<T, NU>(Uc, u0);                                       // (before anything is shifted)
+    T keep[kMpcSlice][NU];
+    const int t0 = chunk * per;
+    if (sliced) {
+#pragma unroll
+        for (int q = 0; q < kMpcSlice; ++q)
+            if (q < per && t0 + q < n_shift) vec_load<T, NU>(Uc + (size_t)(t0 + q + 1) * sU, keep[q]);
+    }
+    __syncthreads();
+    if (sliced) {
+        if (inb) {
+#pragma unroll
+            for (int q = 0; q < kMpcSlice; ++q)
+                if (q < per && t0 + q < n_shift) vec_store<T, NU>(Uc + (size_t)(t0 + q) * sU, keep[q]);
+        }
+    }
+    if (chunk != 0 || !inb) return;
+    T x[NX], xn[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = a.plant_x[(size_t)i * B + b];
-    vec_load<T, NU>(Uc, u);
-    Stepper<T, Dyn>::step(a.plant_integ, a.params, a.dt, x, u, xn);
+    Stepper<T, Dyn>::step(a.plant_integ, a.params, a.dt, x, u0, xn);
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         a.plant_x[(size_t)i * B + b] = xn[i];
@@ -1103,12 +1133,14 @@ __global__ void __launch_bounds__(64) mpc_advance_kernel(MpcArgs<T> a) {
     }
 #pragma unroll
     for (int j = 0; j < NU; ++j)
-        if (a.u_log) a.u_log[((size_t)a.step * B + b) * NU + j] = u[j];
+        if (a.u_log) a.u_log[((size_t)a.step * B + b) * NU + j] = u0[j];
     if (a.cost_log) a.cost_log[(size_t)a.step * B + b] = a.cost[b];
-    for (int t = 0; t + 1 < a.N; ++t) {
-        T un[NU];
-        vec_load<T, NU>(Uc + (t + 1) * sU, un);
-        vec_store<T, NU>(Uc + t * sU, un);
+    if (!sliced) {
+        for (int t = 0; t + 1 < a.N; ++t) {
+            T un[NU];
+            vec_load<T, NU>(Uc + (t + 1) * sU, un);
+            vec_store<T, NU>(Uc + t * sU, un);
+        }
     }
 }
 

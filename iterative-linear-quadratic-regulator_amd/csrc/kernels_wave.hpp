@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(64) linearize_wave_kernel(KArgs<T> a) {
                   oLUU = oLUX + NU * NX;
     const size_t B = a.B;
     const size_t wid = blockIdx.x;
-    const int t = (int)(wid / B);
+    const int t = a.t_first + (int)(wid / B);     // (t_first > 0: the sparse form's launch over t = N-1, N only)
     const int b = (int)(wid % B);
     if (t > a.N || !traj_active(a.status[b])) return;
     const int lane = threadIdx.x;
@@ -86,6 +86,49 @@ __global__ void __launch_bounds__(64) linearize_wave_kernel(KArgs<T> a) {
         }
         out[e] = v;
     }
+}
+
+// ---------------------------------------------------------------------------
+// The sparse form's gradients (KArgs::lin_sparse): l_x, l_u of every (t, b) as one DENSE side tensor [N][B][n_x + n_u]
+// at the front of the expansion buffer (which the sparse form otherwise leaves unused: the constant-matrix sweep takes
+// its matrices from the records of t = N-1 at the buffer's end).  One lane per point.  Round 2 wrote them into their
+// slots of the 3424-byte records with one 64-thread workgroup per point: 513 k workgroups (240 us at B = 1024), and the
+// sweep that followed took 1070 us instead of 630 -- reading 96 fresh bytes out of every 3424-byte record is what was
+// slow (tools/c5_anomaly.py: the sweep is only slow right behind that linearisation, not behind the rollout).  Same
+// sums in the same order as linearize_wave_kernel: bit-identical values.
+// ---------------------------------------------------------------------------
+template <typename T, int NX, int NU>
+__global__ void __launch_bounds__(64) linearize_grad_dense_kernel(KArgs<T> a) {
+    using Dyn = Linear<T, NX, NU>;
+    using PL = ParamLayout<Dyn::NSYS, NX, NU>;
+    const size_t B = a.B;
+    const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const int t = (int)(idx / B);
+    const int b = (int)(idx % B);
+    if (t >= a.N || !traj_active(a.status[b])) return;
+    const int slot = a.cur_slot[b];
+    const T* __restrict__ p = a.params;
+    T x[NX], u[NU];
+    vec_load<T, NX>(a.X + vec_at(B, a.N + 1, NX, slot, t, b), x);
+    vec_load<T, NU>(a.U + vec_at(B, a.N, NU, slot, t, b), u);
+#pragma unroll
+    for (int j = 0; j < NX; ++j) x[j] -= p[PL::XT + j];
+    T g[NX + NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < NX; ++j) acc += p[PL::QS + i * NX + j] * x[j];
+        g[i] = acc * a.dt;
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        T acc = T(0);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) acc += p[PL::RS + i * NU + j] * u[j];
+        g[NX + i] = acc * a.dt;
+    }
+    vec_store<T, NX + NU>(a.lin + ((size_t)t * B + b) * (NX + NU), g);
 }
 
 // ---------------------------------------------------------------------------

@@ -250,7 +250,7 @@ template <typename T, typename Dyn> Ops<T> make_ops() {
         ILQR_LAUNCH((eval_points_kernel<T, Dyn>), dim3((a.npts + 63) / 64), dim3(64), 0, s, a);
     };
     o.mpc_advance = [](const MpcArgs<T>& a, hipStream_t s) {
-        ILQR_LAUNCH((mpc_advance_kernel<T, Dyn>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+        ILQR_LAUNCH((mpc_advance_kernel<T, Dyn>), dim3((a.B + 63) / 64), dim3(64, kMpcChunks), 0, s, a);
     };
     o.n_dev_params = ParamLayout<Dyn::NSYS, NX, NU>::TOTAL;
     o.n_sys_dev = Dyn::NSYS;
@@ -266,6 +266,17 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
     o.lin_stride = 2 * NX * NX + 2 * NX * NU + NX + NU + NU * NU;
     for (int k = 0; k < 5; ++k) {
         o.linearize[k] = [](const KArgs<T>& a, hipStream_t s) {
+            if (a.lin_sparse) {
+                // sparse form: the matrices (and the terminal expansion) from t = N-1 on, the gradients of every point dense
+                KArgs<T> w = a;
+                w.t_first = a.N - 1;
+                LaunchEvents le = launch_events();      // (the phase timer's event pair spans both launches)
+                launch_events() = LaunchEvents{le.a, nullptr};
+                ILQR_LAUNCH((linearize_grad_dense_kernel<T, NX, NU>), dim3((unsigned)(((size_t)a.B * a.N + 63) / 64)), dim3(64), 0, s, a);
+                launch_events() = LaunchEvents{nullptr, le.b};
+                ILQR_LAUNCH((linearize_wave_kernel<T, NX, NU>), dim3((unsigned)((size_t)a.B * 2)), dim3(64), 0, s, w);
+                return;
+            }
             ILQR_LAUNCH((linearize_wave_kernel<T, NX, NU>), dim3((unsigned)((size_t)a.B * (a.N + 1))), dim3(64), 0, s, a);
         };
     }
@@ -316,7 +327,7 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
         ILQR_LAUNCH((eval_points_kernel<T, Dyn>), dim3((a.npts + 63) / 64), dim3(64), 0, s, a);
     };
     o.mpc_advance = [](const MpcArgs<T>& a, hipStream_t s) {
-        ILQR_LAUNCH((mpc_advance_kernel<T, Dyn>), dim3((a.B + 63) / 64), dim3(64), 0, s, a);
+        ILQR_LAUNCH((mpc_advance_kernel<T, Dyn>), dim3((a.B + 63) / 64), dim3(64, kMpcChunks), 0, s, a);
     };
     o.n_dev_params = ParamLayout<Dyn::NSYS, NX, NU>::TOTAL;
     o.n_sys_dev = Dyn::NSYS;
@@ -815,6 +826,7 @@ template <typename T> class SolverT : public SolverBase {
         KArgs<T> a = kargs(s);
         a.reset_slots = s.slots_stale ? 1 : 0;
         a.const_lin = s.lin_const ? 1 : 0;
+        a.lin_sparse = (s.lin_const && !s.lin_full) ? 1 : 0;    // where the CONST sweep finds l_x, l_u (KArgs::lin_sparse)
         timer.begin(ILQR_PHASE_BACKWARD, stream);
         ops.backward(a, stream);
         timer.end(stream);
