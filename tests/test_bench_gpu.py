@@ -47,6 +47,23 @@ def test_headline_line_small():
     assert s["converged"] + s["linesearch_failed"] + s["maxiter"] == 512
 
 
+def test_headline_under_torch_distributed_run_one_rank():
+    """The launcher form the driver uses for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`), with
+    N = 1: RANK / WORLD_SIZE / MASTER_* from the environment, the side-stream status exchange over a one-rank RCCL group."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--batch", "256", "--no-cpu-baseline", "--no-solve-extra", "--exchange", "--exchange-every", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and "exchange" in d and d["all_costs_finite"]
+
+
 def test_headline_materialised_switch():
     d = _bench("--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--no-solve-extra", "--materialised")
     assert "materialised" in d["config"]["iteration_path"] and d["roofline"]["bound"] == "hbm"

@@ -297,6 +297,42 @@ def test_c5_shard_full_shape():
                 P = Q + A.T @ P @ A + A.T @ P @ Bm @ Kt
 
 
+def test_c5_whole_batch_on_one_gpu():
+    """c5 as BASELINE states it for ONE GPU's worth of memory: n = 16, m = 8, N = 500, B = 1024 -- the size at which round 2's
+    sweep ran 1.7x slower inside the iteration than back to back.  Sampled trajectories against
+    the C oracle: K_t, k_t of a sweep around random trajectories (the functional call: sparse linearisation with the
+    dense gradient tensor, constant-matrix MFMA sweep), and a full solve through the iteration path; fp64 at 1e-5
+    element-wise, fp32 at 1e-5 matrix level."""
+    n, m, N, B = 16, 8, 500, 1024
+    p = problems.linear_quadratic(n=n, m=m, N=N)
+    x0, U0 = problems.lq_batch(B, n, m, N)
+    co = COracle(p["dynamics"], p["cost"])
+    rng = np.random.default_rng(7)
+    X, U = rng.standard_normal((B, n, N + 1)), rng.standard_normal((B, m, N))
+    sample = (0, 1, 127, 128, 511, 777, 1023)
+    for dtype in (np.float64, np.float32):
+        sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], dtype)
+        s = ilqr_amd.iLQR(sysm, None, x0, U0, N=N, tol=1e-9, maxiter=3, verbose=False)
+        Xd, Ud = X.astype(dtype).astype(np.float64), U.astype(dtype).astype(np.float64)
+        uff, K = s.backward_pass(Xd, Ud)
+        for b in sample:
+            uff_o, K_o = co.backward_pass(Xd[b], Ud[b])
+            if dtype == np.float64:
+                np.testing.assert_allclose(K[b], K_o, rtol=RTOL, atol=1e-9)
+                np.testing.assert_allclose(uff[b], uff_o, rtol=RTOL, atol=1e-9)
+            _close(K[b], K_o, RTOL, "K")
+            _close(uff[b], uff_o, RTOL, "k")
+        Xs, Us, cost = s.optimize_trajectory()
+        assert np.isfinite(cost).all() and (np.asarray(s.iterations) <= 3).all()
+        for b in sample:
+            r = co.solve(x0[b], U0[b], tol=1e-9, maxiter=3)
+            _close(cost[b], r["cost"], RTOL, "cost")
+            if dtype == np.float64:
+                assert int(s.iterations[b]) == r["iterations"]
+                np.testing.assert_allclose(Us[b], r["U"], rtol=1e-5, atol=1e-8)
+                np.testing.assert_allclose(s.K[b], r["K"], rtol=1e-5, atol=1e-9)
+
+
 def test_c1_as_the_driver_runs_it():
     """c1 exactly as run_iLQR_open_loop.py runs it (:16-69): T = 4 s -> N = 400, backward_euler, ONE trajectory,
     against the committed golden vector (tests/golden/c1_pendulum_be_n400.npz, NumPy oracle)."""

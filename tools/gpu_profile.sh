@@ -35,6 +35,9 @@ timeout -k 10 120 python3 tools/hbm_peak.py > $OUT/hbm_peak.json 2> /dev/null ||
 timeout -k 10 120 ./tools/micro/issue_rate > $OUT/issue_rate.log || exit 1
 timeout -k 10 120 ./tools/micro/range_probe > $OUT/range_probe.log || exit 1
 timeout -k 10 300 python3 tools/f32_error.py > $OUT/f32_error.log 2>&1 || exit 1
+timeout -k 10 600 python3 tools/f32_status_parity.py --out $OUT/status_parity.json > $OUT/status_parity.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/c5_anomaly.py > $OUT/c5_anomaly.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/fused_ab.py --f64 > $OUT/fused_ab.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/c5_sweep.py > $OUT/c5_sweep.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/sweep_scaling.py > $OUT/sweep_scaling.log 2>&1 || exit 1
 cat $OUT/bench_default.json; cat $OUT/bench_f64.json
