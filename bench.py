@@ -403,7 +403,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ and (args.exchange or args.config != "c3")):
+        # under torch.distributed.run (any world size): rendezvous through the launcher's own store
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")  # RCCL
     elif args.exchange or args.config != "c3":

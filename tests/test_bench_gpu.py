@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(*args, timeout=600):
+def _bench(*args, timeout=300):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
                        env=env, cwd=ROOT)
@@ -58,7 +58,7 @@ def test_headline_under_torch_distributed_run_one_rank():
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                         "--batch", "256", "--no-cpu-baseline", "--no-solve-extra", "--exchange", "--exchange-every", "1"],
-                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                       capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and "exchange" in d and d["all_costs_finite"]
