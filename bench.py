@@ -126,6 +126,22 @@ def cpu_baseline(p, dtype, cores, budget_s=10.0, total_core_seconds=None):
                       f"reference loop with its sequential backtracking; {cores} worker processes, {wall:.1f} s"}
 
 
+def rank_barrier(dist, dev):
+    """Barrier over the ranks: RCCL needs the device named; gloo (several ranks rehearsed on one card) takes none."""
+    if dist.get_backend() == "nccl":
+        dist.barrier(device_ids=[dev])
+    else:
+        dist.barrier()
+
+
+def max_over_ranks(torch, dist, value, world):
+    if world <= 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def kernel_table(phases, ab, traffic, names, peak=HBM_PEAK_GBS):
     """{kernel: {avg_launch_us, launches, algorithmic_bytes_per_launch, achieved_GBs, frac_of_8TBs, traffic}} from the
     handle's per-dispatch HIP events (phases: {phase: (ms, launches)}) and its algorithmic byte counts."""
@@ -271,19 +287,16 @@ def run_c4(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist)
     sb.mpc_reset()
     sb.mpc_run(max(args.warmup, 1))       # cold start: the first solves run to maxiter
     if world > 1 or dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     u, x, c = sb.mpc_run(args.steps)
     st = sb.global_status()
     if world > 1 or dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall = float(wall_t.item())
+    wall = max_over_ranks(torch, dist, wall, world)
     if rank == 0:
         print(json.dumps({
             "metric": "MPC instance-steps/sec (8192 warm-started UA double pendulum instances, T=200, n=4 m=1)",
@@ -318,20 +331,17 @@ def run_c5(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist)
     stats = torch.zeros(4, dtype=torch.float64, device="cuda")
     from ilqr_amd.dist import allreduce_status, to_status
     if world > 1 or dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     h.iterate(args.steps)
     h.status_reduce(stats.data_ptr())
     allreduce_status(stats)
     if world > 1 or dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall = float(wall_t.item())
+    wall = max_over_ranks(torch, dist, wall, world)
     st = to_status(stats.cpu())
     if rank == 0:
         print(json.dumps({
@@ -360,6 +370,9 @@ def main():
                     help="f32 = the reference's own (JAX default) precision; f64 = the build's double mode")
     ap.add_argument("--materialised", action="store_true",
                     help="time the four-launch iteration over the materialised expansion (ILQR_FLAG_NO_FUSE) instead of the fused one")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (one rank per GPU); gloo = rehearsal of the N-rank control flow with several ranks "
+                         "on ONE card (tests): ranks map to device LOCAL_RANK % device_count, collectives run on host copies")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-phase-timing", action="store_true")
     ap.add_argument("--no-solve-extra", action="store_true", help="skip the solve_to_convergence / MPC / configs extras (profiling runs)")
@@ -402,11 +415,12 @@ def main():
                          f"(WORLD_SIZE is {world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the measured path")
+    local_rank = local_rank % torch.cuda.device_count()      # (only differs from LOCAL_RANK in the one-card rehearsal)
     torch.cuda.set_device(local_rank)
     if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ and (args.exchange or args.config != "c3")):
         # under torch.distributed.run (any world size): rendezvous through the launcher's own store
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL
+        dist.init_process_group(args.backend)  # nccl = RCCL
     elif args.exchange or args.config != "c3":
         # one rank: the collectives of the sharded configs still go through RCCL (a group of ONE rank)
         import socket
@@ -416,7 +430,7 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1)
     if args.config != "c3":
         (run_c4 if args.config == "c4" else run_c5)(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist)
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
         dist.destroy_process_group()
         return
     exchange = world > 1 or args.exchange
@@ -454,7 +468,7 @@ def main():
         h.flush()                    # the acceptance step of the newest candidates, if the last launch left it pending
         if exchange and xchg.k:
             xchg.result()            # the last exchange has landed on every rank
-            dist.barrier(device_ids=[local_rank])
+            rank_barrier(dist, local_rank)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -509,10 +523,7 @@ def main():
         if hm is not h:
             hm.close()
 
-    wall_t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(wall_t, op=dist.ReduceOp.MAX)
-    wall = float(wall_t.item())
+    wall = max_over_ranks(torch, dist, wall, world)
     cost = h.get(_lib.COST)
     finite = bool(np.isfinite(cost).all())
 
@@ -616,7 +627,7 @@ def main():
             out["configs"] = config_extras(ilqr_amd, _lib, problems, local_rank, stream)
         print(json.dumps(out))
     if world > 1 or args.exchange:
-        dist.barrier(device_ids=[local_rank])
+        rank_barrier(dist, local_rank)
         dist.destroy_process_group()
 
 

@@ -38,6 +38,11 @@ def allreduce_status(stats4, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return stats4      # no process group: a single shard (with a group of ONE rank the collectives still run)
+    if stats4.is_cuda and dist.get_backend(group) == "gloo":
+        # several ranks rehearsed on ONE card (tests, `bench.py --backend gloo`): the collective runs on a host copy
+        host = allreduce_status(stats4.cpu(), group)
+        stats4.copy_(host)
+        return stats4
     mm = torch.stack([-stats4[0], stats4[1]])
     dist.all_reduce(mm, op=dist.ReduceOp.MAX, group=group)
     cnt = stats4[2:4].clone()
@@ -83,6 +88,10 @@ class StatusExchange:
         self.stats = [torch.zeros(4, dtype=torch.float64, device=dev) for _ in range(2)]
         self.gathered = [torch.zeros(self.world, 4, dtype=torch.float64, device=dev) for _ in range(2)]
         self.k = 0
+        # gloo with device tensors (several ranks rehearsed on one card): the gather runs on host copies, blocking
+        self.host_gather = self.cuda and dist.is_initialized() and dist.get_backend(group) == "gloo"
+        if self.host_gather:
+            self.gathered_host = [torch.zeros(self.world, 4, dtype=torch.float64) for _ in range(2)]
         if self.cuda:
             self.side = torch.cuda.Stream(device=dev)
             # one event pair per buffer, re-recorded at every use (creating events per step is host time on a 0.2 ms step)
@@ -98,6 +107,12 @@ class StatusExchange:
         torch, dist = self.torch, self.dist
         i = self.k & 1
         self.k += 1
+        if self.host_gather:
+            fill(self.stats[i])
+            torch.cuda.current_stream().synchronize()
+            dist.all_gather(list(self.gathered_host[i].unbind(0)), self.stats[i].cpu(), group=self.group)
+            self.gathered[i].copy_(self.gathered_host[i])
+            return i
         if self.cuda:
             cur = torch.cuda.current_stream()
             # the collective that last used this buffer pair (two launches ago) must have finished: normally it has, and

@@ -64,6 +64,34 @@ def test_headline_under_torch_distributed_run_one_rank():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and "exchange" in d and d["all_costs_finite"]
 
 
+@pytest.mark.parametrize("extra,unit,total", [(["--batch", "256", "--exchange-every", "1", "--no-cpu-baseline", "--no-solve-extra"], "iLQR iterations/sec", 512),
+                                               (["--config", "c4", "--batch", "64"], "MPC instance-steps/sec", 64),
+                                               (["--config", "c5", "--batch", "32"], "iLQR iterations/sec", 32)])
+def test_two_ranks_rehearsed_on_one_card(extra, unit, total):
+    """The N > 1 control flow of bench.py -- ranks from the launcher's environment, per-rank shards and seeds, the status
+    exchange between iterations, barrier + MAX of the wall time over ranks, one JSON line from rank 0 -- with TWO ranks
+    sharing the one GPU of a test box.  RCCL refuses two ranks on one device, so the collectives run over gloo on host
+    copies (`--backend gloo`); RCCL itself is covered by the one-rank tests.  What an 8-GPU node adds is one rank per card."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--backend", "gloo", *extra], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["unit"] == unit and d["steps"] == 3
+    assert abs(d["value"] - total * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-9
+    if "--config" not in extra:
+        assert d["scaling"] == "weak" and "2 independent shards" in d["config"]["sharding"]
+    else:
+        assert d["config"].get("instances_per_gpu", d["config"].get("batch_per_gpu")) == total // 2
+
+
 def test_headline_materialised_switch():
     d = _bench("--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--no-solve-extra", "--materialised")
     assert "materialised" in d["config"]["iteration_path"] and d["roofline"]["bound"] == "hbm"
