@@ -867,18 +867,24 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
 template <typename T>
 ILQR_DEV bool select_candidates(const KArgs<T>& a, int b, bool last_pass, int& slot_out, int& status_out) {
     const size_t B = a.B;
+    // everything the decision reads is fetched up front, whatever the status turns out to be (all addresses are valid
+    // for any b < B): ONE memory round trip -- a first-match loop that loads as it goes serialised up to n_pass of them
+    // (most of select_kernel's former 8 us), and loads behind the status test were a second one at the head of the
+    // fused kernel, where the whole workgroup waits for this lane
     int st = a.status[b];
     int slot = a.cur_slot[b];
+    const int acc_in = a.accepted[b];
+    const T c0 = a.cost[b];
+    T cs[kMaxAlpha];
+#pragma unroll
+    for (int ai = 0; ai < kMaxAlpha; ++ai) cs[ai] = ai < a.n_pass ? a.costs[(size_t)ai * B + b] : T(0);
+    const int it_in = a.iters[b];
+    const T cp_in = a.cost_prev[b];
+    T cost_now = c0, cost_before = cp_in;      // cost / cost_prev as they stand after this pass
     bool still_active = false;
     if (traj_active(st)) {
-        int acc = a.accepted[b];
-        const T c0 = a.cost[b];
+        int acc = acc_in;
         if (!acc) {
-            // all candidate costs are fetched before any is looked at: a first-match loop that loads as it
-            // goes serialises up to n_pass memory round trips (measured: most of this kernel's 8 us)
-            T cs[kMaxAlpha];
-#pragma unroll
-            for (int ai = 0; ai < kMaxAlpha; ++ai) cs[ai] = ai < a.n_pass ? a.costs[(size_t)ai * B + b] : T(0);
             int first = -1;
 #pragma unroll
             for (int ai = kMaxAlpha - 1; ai >= 0; --ai)
@@ -892,11 +898,13 @@ ILQR_DEV bool select_candidates(const KArgs<T>& a, int b, bool last_pass, int& s
                 a.cost_prev[b] = c0;
                 a.cost[b] = c;
                 a.alpha_taken[b] = al;
+                cost_now = c;
+                cost_before = c0;
                 acc = 1;
             }
         }
         if (last_pass) {
-            const int it = a.iters[b] + 1;
+            const int it = it_in + 1;
             a.iters[b] = it;
             a.accepted[b] = 0;
             if (!(a.flags & ILQR_FLAG_KEEP_ITERATING)) {
@@ -905,7 +913,7 @@ ILQR_DEV bool select_candidates(const KArgs<T>& a, int b, bool last_pass, int& s
                 } else if (it >= a.maxiter) {
                     st = (st & ~0xff) | ILQR_TRAJ_MAXITER;
                 } else {
-                    const T d = M<T>::abs(a.cost[b] - a.cost_prev[b]);
+                    const T d = M<T>::abs(cost_now - cost_before);
                     if (d <= a.tol) st = (st & ~0xff) | ILQR_TRAJ_CONVERGED;
                 }
                 a.status[b] = st;
