@@ -34,16 +34,21 @@ namespace ilqr {
 // two tiles in LDS (48 + padding: the 16-byte writes of 8 neighbouring lanes then fall into distinct banks in fp32 --
 // 52 dwords; fp64 keeps its tiles 32-byte aligned for the double4 reads of the sweep and takes a two-way conflict on
 // the writes)
-template <typename T, int TPW> struct FusedCfg;
-template <> struct FusedCfg<float, 16> { static constexpr int P = 8, RU = 8, TILE = 52; };
-template <> struct FusedCfg<double, 16> { static constexpr int P = 4, RU = 4, TILE = 52; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
-template <> struct FusedCfg<float, 4> { static constexpr int P = 3, RU = 4, TILE = 52; };
-template <> struct FusedCfg<double, 4> { static constexpr int P = 3, RU = 3, TILE = 52; };
+// PK (fp32, TPW = 16, explicit integrators): the producers evaluate TWO time steps per lane in packed FP32 -- the
+// system, integrator and cost templates instantiated on a float pair (dynamics.hpp, pair_f32): 817 vector instructions
+// for two points against 989 for one, bit-identical values.  A unit is then 128 tiles; four producer waves (the pair
+// form needs ~200 VGPRs: 512-thread workgroups) produce as many points per pass as eight scalar ones.
+template <typename T, int TPW, bool PK> struct FusedCfg;
+template <> struct FusedCfg<float, 16, false> { static constexpr int P = 8, RU = 8, TILE = 52; };
+template <> struct FusedCfg<float, 16, true> { static constexpr int P = 4, RU = 4, TILE = 52; };
+template <> struct FusedCfg<double, 16, false> { static constexpr int P = 4, RU = 4, TILE = 52; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
+template <> struct FusedCfg<float, 4, false> { static constexpr int P = 3, RU = 4, TILE = 52; };
+template <> struct FusedCfg<double, 4, false> { static constexpr int P = 3, RU = 3, TILE = 52; };
 
-template <typename T, int TPW> constexpr int fused_lds_bytes() {
-    return FusedCfg<T, TPW>::RU * 64 * FusedCfg<T, TPW>::TILE * (int)sizeof(T) + (FusedCfg<T, TPW>::RU + 4 + 32 + 4) * 4;
+template <typename T, int TPW, bool PK> constexpr int fused_lds_bytes() {
+    return FusedCfg<T, TPW, PK>::RU * (PK ? 128 : 64) * FusedCfg<T, TPW, PK>::TILE * (int)sizeof(T) + (FusedCfg<T, TPW, PK>::RU + 4 + 32 + 4) * 4;
 }
-template <typename T, int TPW> constexpr int fused_threads() { return 64 * (TPW / 4 + FusedCfg<T, TPW>::P); }
+template <typename T, int TPW, bool PK> constexpr int fused_threads() { return 64 * (TPW / 4 + FusedCfg<T, TPW, PK>::P); }
 
 // the sweep's view of a tile in LDS, and the step that consumes it
 template <typename T> struct FusedStep;
@@ -77,16 +82,21 @@ ILQR_DEV void compiler_fence() { asm volatile("" ::: "memory"); }
 ILQR_DEV int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 ILQR_DEV void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <typename T, typename Dyn, int INTEG, int TPW>
-__global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_kernel(KArgs<T> a) {
+template <typename T, typename Dyn, int INTEG, int TPW, bool PK>
+__global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused16_kernel(KArgs<T> a) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     static_assert(NU == 1 && NX >= 2 && NX <= 4, "the fused sweep serves the n_u = 1 DPP tile");
     static_assert(TPW == 16 || TPW == 4, "16 or 4 trajectories per workgroup");
-    using Cfg = FusedCfg<T, TPW>;
+    static_assert(!PK || (sizeof(T) == 4 && TPW == 16 && INTEG != ILQR_INT_BACKWARD_EULER), "pair producers: fp32, 16-trajectory workgroups, explicit integrators");
+    using Cfg = FusedCfg<T, TPW, PK>;
     constexpr int P = Cfg::P, RU = Cfg::RU, TL = Cfg::TILE;
     constexpr int NSW = TPW / 4;                 // sweep waves
-    constexpr int US = 64 / TPW;                 // time steps per unit (a producer wave = 64 tiles)
-    constexpr int UNIT = 64 * TL;                // scalars per ring slot
+    constexpr int UT = PK ? 128 : 64;            // tiles per unit (one pass of a producer wave)
+    constexpr int US = UT / TPW;                 // time steps per unit
+    constexpr int UNIT = UT * TL;                // scalars per ring slot
+    // where the tile of (step r of the unit, trajectory tl) sits in its ring slot: step-major, or -- pair producers --
+    // the two steps a lane evaluates together next to each other
+    auto tile_off = [](int r, int tl) { return PK ? ((r / 2) * TPW + tl) * 2 * TL + (r % 2) * TL : (r * TPW + tl) * TL; };
     constexpr int R = gain_record(NX, 1);
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
     using V4 = typename Vec4<T>::type;
@@ -99,6 +109,8 @@ __global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_ke
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b0 = blockIdx.x * TPW;
+    ClockProbe cp;       // (diagnostic, ILQR_CLOCK_PROBE: start / end ticks of every workgroup's thread 0 = its first sweep wave)
+    cp.start();
     const size_t B = a.B;
     const int N = a.N;
 
@@ -182,7 +194,8 @@ __global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_ke
         using FS = FusedStep<T>;
         int goff = (N - 1) * rstride;
         // this trajectory's tile of time step r of unit k sits at unit_base(k) + r * TPW * TL: a compile-time offset per step
-        auto unit_base = [&](int k) -> const T* { return ring + (size_t)(k % RU) * UNIT + tl * TL; };
+        auto unit_base = [&](int k) -> const T* { return ring + (size_t)(k % RU) * UNIT + tile_off(0, tl); };
+        constexpr auto step_off = [](int r) { return PK ? (r / 2) * TPW * 2 * TL + (r % 2) * TL : r * TPW * TL; };
         auto one_step = [&](const typename FS::Tile& c) {
             T Kj, kff;
             bool pd;
@@ -195,8 +208,15 @@ __global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_ke
         // the tile of step s + 1 is read from LDS while step s computes.  The flag of the next unit is fetched one step
         // before it is needed, so its LDS round trip is not exposed either.
         typename FS::Tile tq[2];
+#ifdef ILQR_FUSED_STAMPS   // diagnostic build (tools/fused_stamps.py): where a sweep wave's time goes
+        const long long st_t0 = __builtin_readcyclecounter();
+        long long st_spin = 0;
+#endif
         while (lds_peek(&ready[0]) < 1) __builtin_amdgcn_s_sleep(1);
         compiler_fence();
+#ifdef ILQR_FUSED_STAMPS
+        const long long st_first = __builtin_readcyclecounter();
+#endif
         FS::load(tq[0], unit_base(0), i, j, l16);
         const int n_full = N / US, rem = N % US;
         for (int k = 0; k < n_full; ++k) {
@@ -207,13 +227,19 @@ __global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_ke
             for (int r = 0; r < US; ++r) {
                 if (r == US - 2 && more) flag = lds_peek(&ready[(k + 1) % RU]);
                 if (r < US - 1) {
-                    FS::load(tq[(r + 1) & 1], ub + (r + 1) * TPW * TL, i, j, l16);
+                    FS::load(tq[(r + 1) & 1], ub + step_off(r + 1), i, j, l16);
                 } else if (more) {
+#ifdef ILQR_FUSED_STAMPS
+                    const long long w0 = __builtin_readcyclecounter();
+#endif
                     while (flag < k + 2) {
                         __builtin_amdgcn_s_sleep(1);
                         flag = lds_peek(&ready[(k + 1) % RU]);
                     }
                     compiler_fence();
+#ifdef ILQR_FUSED_STAMPS
+                    st_spin += __builtin_readcyclecounter() - w0;
+#endif
                     FS::load(tq[0], unit_base(k + 1), i, j, l16);
                 }
                 one_step(tq[r & 1]);
@@ -227,12 +253,89 @@ __global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_ke
 #pragma unroll
             for (int r = 0; r < US - 1; ++r) {
                 if (r < rem) {
-                    if (r + 1 < rem) FS::load(tq[(r + 1) & 1], ub + (r + 1) * TPW * TL, i, j, l16);
+                    if (r + 1 < rem) FS::load(tq[(r + 1) & 1], ub + step_off(r + 1), i, j, l16);
                     one_step(tq[r & 1]);
                 }
             }
         }
+#ifdef ILQR_FUSED_STAMPS
+        if (a.probe && blockIdx.x == 7 && tid == 0) {
+            a.probe[5] = st_first - st_t0;                              // head of the sweep role -> first unit ready
+            a.probe[6] = st_spin;                                       // waiting for later units
+            a.probe[7] = __builtin_readcyclecounter() - st_first;       // first unit ready -> last step done
+        }
+#endif
+        cp.stop(a.probe, 0);
         if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
+    } else if constexpr (PK) {
+        // ================= pair producers: lane = (trajectory tl, time steps 2 r2 and 2 r2 + 1 of the unit) ===========
+        using T2 = pair_f32;
+        using Dyn2 = typename Dyn::template rebind<T2>;
+        const int pw = wave - NSW;
+        const int tl = lane % TPW, r2 = lane / TPW;
+        const int gidx = b0 + tl;
+        const bool valid = gidx < a.B;
+        const int b = valid ? gidx : a.B - 1;
+        const bool actb = valid && traj_active(s_stat[tl]);
+        const int slot = actb ? s_slot[tl] : 0;
+        const bool move = actb && slot != 0;
+        T pl[PL::TOTAL];
+#pragma unroll
+        for (int q = 0; q < PL::TOTAL; ++q) pl[q] = a.params[q];
+        const SplatParams p{pl};
+        const T2 dt2 = a.dt;
+        for (int k = pw; k < n_units; k += P) {
+            const int ta = N - 1 - k * US - 2 * r2, tb = ta - 1;      // half x: the later step, half y: the one before it
+            const bool ina = ta >= 0, inb = tb >= 0;
+            const int tta = ina ? ta : 0, ttb = inb ? tb : 0;
+            T xa[NX], ua[NU], xb[NX], ub[NU];
+            vec_load<T, NX>(a.X + vec_at(B, N + 1, NX, slot, tta, b), xa);
+            vec_load<T, NU>(a.U + vec_at(B, N, NU, slot, tta, b), ua);
+            vec_load<T, NX>(a.X + vec_at(B, N + 1, NX, slot, ttb, b), xb);
+            vec_load<T, NU>(a.U + vec_at(B, N, NU, slot, ttb, b), ub);
+            if (move && ina) {
+                vec_store<T, NX>(a.X + vec_at(B, N + 1, NX, 0, tta, b), xa);
+                vec_store<T, NU>(a.U + vec_at(B, N, NU, 0, tta, b), ua);
+            }
+            if (move && inb) {
+                vec_store<T, NX>(a.X + vec_at(B, N + 1, NX, 0, ttb, b), xb);
+                vec_store<T, NU>(a.U + vec_at(B, N, NU, 0, ttb, b), ub);
+            }
+            T2 x[NX], u[NU], xn[NX], fx[NX][NX], fu[NX][NU];
+#pragma unroll
+            for (int q = 0; q < NX; ++q) { x[q].x = xa[q]; x[q].y = xb[q]; }
+#pragma unroll
+            for (int q = 0; q < NU; ++q) { u[q].x = ua[q]; u[q].y = ub[q]; }
+            Stepper<T2, Dyn2>::step_jac(INTEG, p, dt2, x, u, xn, fx, fu);
+            T2 gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
+            Cost<T2, Dyn2>::grad(p, dt2, x, u, gxn, gu1);
+            Cost<T2, Dyn2>::hess(p, dt2, x, u, lxxn, luxn, luu);
+            V4 tile_a[12], tile_b[12];
+            tile16_fill<T, NX, NU>([](T2 v) { return v.x; }, fx, fu, gxn, gu1, lxxn, luxn, luu, tile_a);
+            tile16_fill<T, NX, NU>([](T2 v) { return v.y; }, fx, fu, gxn, gu1, lxxn, luxn, luu, tile_b);
+            if (k >= RU) {
+                const int need = k - RU + 1;
+                auto slowest = [&]() {
+                    int m = lds_peek(&done[0]);
+#pragma unroll
+                    for (int q = 1; q < NSW; ++q) m = min(m, lds_peek(&done[q]));
+                    return m;
+                };
+                while (slowest() < need) __builtin_amdgcn_s_sleep(2);
+            }
+            compiler_fence();
+            V4* dst = reinterpret_cast<V4*>(ring + (size_t)(k % RU) * UNIT + tile_off(2 * r2, tl));
+            if (ina) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) dst[q] = tile_a[q];
+            }
+            if (inb) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) dst[TL / 4 + q] = tile_b[q];
+            }
+            compiler_fence();
+            if (lane == 0) lds_poke(&ready[k % RU], k + 1);
+        }
     } else {
         // ================= producers: lane = (trajectory tl, time step r of the unit) ================================
         const int pw = wave - NSW;
@@ -277,7 +380,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW>())) backward_fused16_ke
                 constexpr int NQ = 12 * (int)sizeof(V4) / 16;       // 16-byte pieces of the tile
                 vec_u4 w[NQ];
                 __builtin_memcpy(w, tile, sizeof(V4) * 12);
-                vec_u4* dst = reinterpret_cast<vec_u4*>(ring + (size_t)(k % RU) * UNIT + (r * TPW + tl) * TL);
+                vec_u4* dst = reinterpret_cast<vec_u4*>(ring + (size_t)(k % RU) * UNIT + tile_off(r, tl));
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) dst[q] = w[q];
             }

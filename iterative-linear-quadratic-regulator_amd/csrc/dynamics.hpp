@@ -152,6 +152,38 @@ ILQR_DEV double fast_rsqrt(double x) {
     return r * fma(-0.5 * x, r * r, 1.5);
 }
 
+// ---- two points per lane in packed FP32 ---------------------------------------------------------------------
+// The templates below (systems, integrators, costs) are written on a scalar type T; instantiated on a float PAIR
+// (clang's ext_vector_type(2): element-wise + - * /, a * b + c contracted to v_pk_fma_f32) every lane evaluates two
+// (trajectory, time) points at the issue cost of one: v_pk_fma_f32 issues at the rate of v_fma_f32
+// (tools/micro/pk_rate.hip).  Each half runs exactly the scalar code's operations in the scalar code's order, so the
+// results are bit-identical to two scalar evaluations.  Used by the producers of backward_fused16_kernel.  The
+// parameter block stays scalar (SGPRs): SplatParams presents it as pairs.  Backward Euler (a data-dependent Newton
+// loop) has no pair form: is_scalar guards it.
+typedef float pair_f32 __attribute__((ext_vector_type(2)));
+template <typename T> struct is_scalar { static constexpr bool value = true; };
+template <> struct is_scalar<pair_f32> { static constexpr bool value = false; };
+template <> struct M<pair_f32> {
+    static ILQR_DEV pair_f32 sqrt(pair_f32 x) { return x; }   // (backward Euler only: never instantiated for pairs)
+    static ILQR_DEV pair_f32 abs(pair_f32 x) { return x; }
+    static ILQR_DEV void sincos2(pair_f32 x0, pair_f32 x1, pair_f32* s0, pair_f32* c0, pair_f32* s1, pair_f32* c1) {
+        M<float>::sincos_pk(x0, s0, c0);
+        M<float>::sincos_pk(x1, s1, c1);
+    }
+    static ILQR_DEV void sincos(pair_f32 x, pair_f32* sn, pair_f32* cs) { M<float>::sincos_pk(x, sn, cs); }
+};
+ILQR_DEV pair_f32 fast_rcp(pair_f32 x) {
+    pair_f32 r;
+    r.x = __builtin_amdgcn_rcpf(x.x);
+    r.y = __builtin_amdgcn_rcpf(x.y);
+    const pair_f32 one = 1.0f;
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-x, r, one), r, r);
+}
+struct SplatParams {
+    const float* q;
+    ILQR_DEV pair_f32 operator[](int i) const { pair_f32 r = q[i]; return r; }
+};
+
 // ---------------------------------------------------------------------------
 // Device parameter block (scalars of type T, built on the host in double by
 // build_device_params() in ilqr_abi.hip):
@@ -174,15 +206,16 @@ template <int NSYS, int NX, int NU> struct ParamLayout {
 
 // ---- pendulum (pendulum_sys.py:60-75): derived constants [g/l, d] ------------
 template <typename T> struct Pendulum {
+    template <typename S> using rebind = Pendulum<S>;
     static constexpr int NX = 2, NU = 1, NSYS = 2, ID = ILQR_SYS_PENDULUM;
     static constexpr bool SECOND_ORDER = true;
-    static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
+    template <typename P> static ILQR_DEV void f(P p, const T* x, const T* u, T* xd) {
         xd[0] = x[1];
         T s, c;
         M<T>::sincos(x[0], &s, &c);
         xd[1] = u[0] - p[1] * x[1] - p[0] * s;
     }
-    static ILQR_DEV void fjac(const T* __restrict__ p, const T* x, const T* u, T* xd, T (*Jx)[2], T (*Ju)[1]) {
+    template <typename P> static ILQR_DEV void fjac(P p, const T* x, const T* u, T* xd, T (*Jx)[2], T (*Ju)[1]) {
         T s, c;
         M<T>::sincos(x[0], &s, &c);
         xd[0] = x[1];
@@ -197,11 +230,12 @@ template <typename T> struct Pendulum {
 // derived constants: [a = m2 l1 l2, c11 = m1 l1^2/4 + m2 l1^2 + m2 l2^2/4 + th1 + th2,
 //                     c12 = m2 l2^2/4 + th2 (= m22), gA = m2 g l2/2, gB = (m2 + m1/2) g l1, d1, d2]
 template <typename T, int NU_> struct DoublePendulum {
+    template <typename S> using rebind = DoublePendulum<S, NU_>;
     static constexpr int NX = 4, NU = NU_, NSYS = 7;
     static constexpr bool SECOND_ORDER = true;
     static constexpr int ID = (NU_ == 1) ? ILQR_SYS_UA_DOUBLE_PENDULUM : ILQR_SYS_DOUBLE_PENDULUM;
 
-    static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
+    template <typename P> static ILQR_DEV void f(P p, const T* x, const T* u, T* xd) {
         const T a = p[0], c11 = p[1], c12 = p[2], gA = p[3], gB = p[4], d1 = p[5], d2 = p[6];
         const T q1 = x[0], q2 = x[1], q1d = x[2], q2d = x[3];
         // sin(q1 + q2) by the addition theorem: two reductions per evaluation instead of three
@@ -268,7 +302,7 @@ template <typename T, int NU_> struct DoublePendulum {
     }
 
     // M qdd = h  =>  d qdd = M^-1 (dh - dM qdd)
-    static ILQR_DEV void fjac(const T* __restrict__ p, const T* x, const T* u, T* xd, T (*Jx)[4], T (*Ju)[NU]) {
+    template <typename P> static ILQR_DEV void fjac(P p, const T* x, const T* u, T* xd, T (*Jx)[4], T (*Ju)[NU]) {
         const T a = p[0], c11 = p[1], c12 = p[2], gA = p[3], gB = p[4], d1 = p[5], d2 = p[6];
         const T q1 = x[0], q2 = x[1], q1d = x[2], q2d = x[3];
         T s1, c1, s2, c2;
@@ -312,8 +346,9 @@ template <typename T, int NU_> struct DoublePendulum {
 // ---- linear system x_dot = A x + B u (matlab/CLASSES/Linear_iLQR_CLASS.m:56-60)
 // derived constants: A (n*n), B (n*m) row-major
 template <typename T, int NX_, int NU_> struct Linear {
+    template <typename S> using rebind = Linear<S, NX_, NU_>;
     static constexpr int NX = NX_, NU = NU_, NSYS = NX_ * NX_ + NX_ * NU_, ID = ILQR_SYS_LINEAR;
-    static ILQR_DEV void f(const T* __restrict__ p, const T* x, const T* u, T* xd) {
+    template <typename P> static ILQR_DEV void f(P p, const T* x, const T* u, T* xd) {
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             T acc = T(0);
@@ -324,7 +359,7 @@ template <typename T, int NX_, int NU_> struct Linear {
             xd[i] = acc;
         }
     }
-    static ILQR_DEV void fjac(const T* __restrict__ p, const T* x, const T* u, T* xd, T (*Jx)[NX_], T (*Ju)[NU_]) {
+    template <typename P> static ILQR_DEV void fjac(P p, const T* x, const T* u, T* xd, T (*Jx)[NX_], T (*Ju)[NU_]) {
         f(p, x, u, xd);
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
@@ -423,7 +458,7 @@ template <typename T, typename Dyn> struct Stepper {
 
     // backward Euler quasi-Newton (system_base.py:88-140): explicit-Euler guess, one
     // Jacobian I - dt*J_x at the guess reused, stop at ||F||_2 <= 1e-5 or 20 iterations.
-    static ILQR_DEV void backward_euler(const T* __restrict__ p, T dt, const T* x, const T* u, T* xn) {
+    template <typename P> static ILQR_DEV void backward_euler(P p, T dt, const T* x, const T* u, T* xn) {
         T k[NX], Jx[NX][NX], Ju[NX][NU];
         Dyn::f(p, x, u, k);
 #pragma unroll
@@ -457,7 +492,7 @@ template <typename T, typename Dyn> struct Stepper {
         }
     }
 
-    static ILQR_DEV void step(int integ, const T* __restrict__ p, T dt, const T* x, const T* u, T* xn) {
+    template <typename P> static ILQR_DEV void step(int integ, P p, T dt, const T* x, const T* u, T* xn) {
         T k1[NX];
         if (integ == ILQR_INT_DISCRETE) { Dyn::f(p, x, u, xn); return; }
         if (integ == ILQR_INT_EULER || !SMALL) {
@@ -498,7 +533,7 @@ template <typename T, typename Dyn> struct Stepper {
                     xn[i] = x[i] + (dt / T(6)) * (k1[i] + T(2) * k2[i] + T(2) * k3[i] + k4[i]);
                 return;
             }
-            backward_euler(p, dt, x, u, xn);
+            if constexpr (is_scalar<T>::value) backward_euler(p, dt, x, u, xn);
         }
     }
 
@@ -519,7 +554,7 @@ template <typename T, typename Dyn> struct Stepper {
     // one explicit stage of the chain rule: given the stage point xs = x + c*k_prev with
     // d xs/dx = I + c*Kx_prev, d xs/du = c*Ku_prev, evaluate k = f_c(xs, u) and
     // Kx = J_x(xs) (I + c Kx_prev), Ku = J_x(xs) (c Ku_prev) + J_u(xs).
-    static ILQR_DEV void stage(const T* __restrict__ p, const T* x, const T* u, T c, const T* kprev,
+    template <typename P> static ILQR_DEV void stage(P p, const T* x, const T* u, T c, const T* kprev,
                                const T (*Kxp)[NX], const T (*Kup)[NU], T* k, T (*Kx)[NX], T (*Ku)[NU]) {
         T xs[NX], Jx[NX][NX], Ju[NX][NU], Dx[NX][NX], Du[NX][NU];
 #pragma unroll
@@ -571,7 +606,7 @@ template <typename T, typename Dyn> struct Stepper {
     }
 
     // f, f_x, f_u of the discrete map at (x, u)
-    static ILQR_DEV void step_jac(int integ, const T* __restrict__ p, T dt, const T* x, const T* u, T* xn,
+    template <typename P> static ILQR_DEV void step_jac(int integ, P p, T dt, const T* x, const T* u, T* xn,
                                   T (*fx)[NX], T (*fu)[NU]) {
         T k1[NX];
         if (integ == ILQR_INT_DISCRETE) { Dyn::fjac(p, x, u, xn, fx, fu); return; }
@@ -642,6 +677,7 @@ template <typename T, typename Dyn> struct Stepper {
             }
             // backward Euler: implicit-function theorem at the converged point
             // (system_base.py:146-188): f_x = (I - dt J_x)^-1, f_u = (I - dt J_x)^-1 dt J_u
+            if constexpr (is_scalar<T>::value) {
             backward_euler(p, dt, x, u, xn);
             T Jx[NX][NX], Ju[NX][NU], J[NX][NX], rhs[NX][NX + NU];
             Dyn::fjac(p, xn, u, k1, Jx, Ju);
@@ -659,6 +695,7 @@ template <typename T, typename Dyn> struct Stepper {
                 for (int j = 0; j < NX; ++j) fx[i][j] = rhs[i][j];
 #pragma unroll
                 for (int j = 0; j < NU; ++j) fu[i][j] = rhs[i][NX + j];
+            }
             }
         }
     }
@@ -686,7 +723,7 @@ template <typename T, typename Dyn> struct Cost {
 #endif
 
     // l(x,u) = (0.5 dx'Q dx + 0.5 u'R u) * dt
-    static ILQR_DEV T stage(const T* __restrict__ p, T dt, const T* x, const T* u) {
+    template <typename P> static ILQR_DEV T stage(P p, T dt, const T* x, const T* u) {
         if constexpr (CUSTOM) {
             return Dyn::l(x, u);
         } else if constexpr (sizeof(T) == 4 && NX == 4 && stage_cost_packed) {
@@ -740,7 +777,7 @@ template <typename T, typename Dyn> struct Cost {
         }
     }
     // l_f(x) = 0.5 dx'Q_f dx   (not scaled by dt)
-    static ILQR_DEV T terminal(const T* __restrict__ p, const T* x) {
+    template <typename P> static ILQR_DEV T terminal(P p, const T* x) {
         if constexpr (CUSTOM) {
             return Dyn::lf(x);
         } else {
@@ -758,7 +795,7 @@ template <typename T, typename Dyn> struct Cost {
         }
     }
     // gradient of the stage cost: l_x (n_x), l_u (n_u)
-    static ILQR_DEV void grad(const T* __restrict__ p, T dt, const T* x, const T* u, T* lx, T* lu) {
+    template <typename P> static ILQR_DEV void grad(P p, T dt, const T* x, const T* u, T* lx, T* lu) {
         if constexpr (CUSTOM) {
             T lxx[NX][NX], lux[NU][NX], luu[NU][NU];
             Dyn::l_derivs(x, u, lx, lu, lxx, lux, luu);   // inlined: the unused second derivatives fold away
@@ -780,7 +817,7 @@ template <typename T, typename Dyn> struct Cost {
         }
     }
     // second derivatives of the stage cost: l_xx (n_x x n_x), l_ux (n_u x n_x, system_base.py:216), l_uu
-    static ILQR_DEV void hess(const T* __restrict__ p, T dt, const T* x, const T* u, T (*lxx)[NX], T (*lux)[NX],
+    template <typename P> static ILQR_DEV void hess(P p, T dt, const T* x, const T* u, T (*lxx)[NX], T (*lux)[NX],
                               T (*luu)[NU]) {
         if constexpr (CUSTOM) {
             T lx[NX], lu[NU];
@@ -799,7 +836,7 @@ template <typename T, typename Dyn> struct Cost {
             }
         }
     }
-    static ILQR_DEV void l_f_x(const T* __restrict__ p, const T* x, T* out) {
+    template <typename P> static ILQR_DEV void l_f_x(P p, const T* x, T* out) {
         if constexpr (CUSTOM) {
             T H[NX][NX];
             Dyn::lf_derivs(x, out, H);
@@ -813,7 +850,7 @@ template <typename T, typename Dyn> struct Cost {
             }
         }
     }
-    static ILQR_DEV void l_f_xx(const T* __restrict__ p, const T* x, T (*H)[NX]) {
+    template <typename P> static ILQR_DEV void l_f_xx(P p, const T* x, T (*H)[NX]) {
         if constexpr (CUSTOM) {
             T g[NX];
             Dyn::lf_derivs(x, g, H);

@@ -146,17 +146,15 @@ namespace ilqr {
 // (Stepper::step_jac); the cost derivatives are evaluated here.  n_x < 4 is zero-padded to the 4 x 4 tile (padding
 // states have no dynamics and no cost).  Shared by linearize_kernel and backward_fused16_kernel.
 // ---------------------------------------------------------------------------
-template <typename T, typename Dyn>
-ILQR_DEV void tile16_pack(const T* __restrict__ p, T dt, const T* x, const T* u, const T (*fx)[Dyn::NX],
-                          const T (*fu)[Dyn::NU], typename Vec4<T>::type* tile) {
-    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+// tile16_fill<TS>: the packing proper, from the expansion's terms in a scalar type T (T = TS, pick = identity) or in the
+// float pair of the two-points-per-lane producers (pick = one half).
+template <typename TS, int NX, int NU, typename T, typename Pick>
+ILQR_DEV void tile16_fill(Pick pick, const T (*fx)[NX], const T (*fu)[NU], const T* gxn, const T* gu1, const T (*lxxn)[NX],
+                          const T (*luxn)[NX], const T (*luu)[NU], typename Vec4<TS>::type* tile) {
     static_assert((NX >= 2 && NX <= 4 && NU == 1) || (NX == 4 && NU == 2), "tile packing: n_x <= 4 with n_u = 1, or (4, 2)");
-    T gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
-    Cost<T, Dyn>::grad(p, dt, x, u, gxn, gu1);
-    Cost<T, Dyn>::hess(p, dt, x, u, lxxn, luxn, luu);
     // zero-pad to the 4 x 4 tile (a no-op for n_x = 4): padding states have no dynamics and no cost
-    auto F = [&](int i, int j) -> T { return (i < NX && j < NX) ? fx[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
-    auto L = [&](int i, int j) -> T { return (i < NX && j < NX) ? lxxn[i < NX ? i : 0][j < NX ? j : 0] : T(0); };
+    auto F = [&](int i, int j) -> TS { return (i < NX && j < NX) ? pick(fx[i < NX ? i : 0][j < NX ? j : 0]) : TS(0); };
+    auto L = [&](int i, int j) -> TS { return (i < NX && j < NX) ? pick(lxxn[i < NX ? i : 0][j < NX ? j : 0]) : TS(0); };
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         tile[c].x = F((c + 0) & 3, c); tile[c].y = F((c + 1) & 3, c);
@@ -171,24 +169,34 @@ ILQR_DEV void tile16_pack(const T* __restrict__ p, T dt, const T* x, const T* u,
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int jj = j < NX ? j : 0;
-            tile[8 + j].x = j < NX ? fu[jj][0] : T(0);
-            tile[8 + j].y = j < NX ? gxn[jj] : T(0);
-            tile[8 + j].z = j < NX ? luxn[0][jj] : T(0);
-            tile[8 + j].w = (j == 0) ? gu1[0] : ((j == 1) ? luu[0][0] : T(0));
+            tile[8 + j].x = j < NX ? pick(fu[jj][0]) : TS(0);
+            tile[8 + j].y = j < NX ? pick(gxn[jj]) : TS(0);
+            tile[8 + j].z = j < NX ? pick(luxn[0][jj]) : TS(0);
+            tile[8 + j].w = (j == 0) ? pick(gu1[0]) : ((j == 1) ? pick(luu[0][0]) : TS(0));
         }
     } else {
         // group j: f_u[j][0], f_u[j][1], l_x[j], l_ux[0][j] | l_ux[1][j], e0, e1, e2   (backward_tile16m2.hpp);
         // the sweep's Q_uu is symmetric: the mean of l_uu[0][1] and l_uu[1][0] is stored
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            tile[8 + 2 * j].x = fu[j][0]; tile[8 + 2 * j].y = fu[j][NU - 1];
-            tile[8 + 2 * j].z = gxn[j]; tile[8 + 2 * j].w = luxn[0][j];
-            tile[9 + 2 * j].x = luxn[NU - 1][j];
-            tile[9 + 2 * j].y = (j == 0) ? gu1[0] : ((j == 1) ? T(0.5) * (luu[0][NU - 1] + luu[NU - 1][0]) : T(0));
-            tile[9 + 2 * j].z = (j == 0) ? gu1[NU - 1] : ((j == 1) ? luu[NU - 1][NU - 1] : T(0));
-            tile[9 + 2 * j].w = (j == 0) ? luu[0][0] : T(0);
+            tile[8 + 2 * j].x = pick(fu[j][0]); tile[8 + 2 * j].y = pick(fu[j][NU - 1]);
+            tile[8 + 2 * j].z = pick(gxn[j]); tile[8 + 2 * j].w = pick(luxn[0][j]);
+            tile[9 + 2 * j].x = pick(luxn[NU - 1][j]);
+            tile[9 + 2 * j].y = (j == 0) ? pick(gu1[0]) : ((j == 1) ? TS(0.5) * (pick(luu[0][NU - 1]) + pick(luu[NU - 1][0])) : TS(0));
+            tile[9 + 2 * j].z = (j == 0) ? pick(gu1[NU - 1]) : ((j == 1) ? pick(luu[NU - 1][NU - 1]) : TS(0));
+            tile[9 + 2 * j].w = (j == 0) ? pick(luu[0][0]) : TS(0);
         }
     }
+}
+
+template <typename T, typename Dyn, typename P>
+ILQR_DEV void tile16_pack(P p, T dt, const T* x, const T* u, const T (*fx)[Dyn::NX],
+                          const T (*fu)[Dyn::NU], typename Vec4<T>::type* tile) {
+    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+    T gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
+    Cost<T, Dyn>::grad(p, dt, x, u, gxn, gu1);
+    Cost<T, Dyn>::hess(p, dt, x, u, lxxn, luxn, luu);
+    tile16_fill<T, NX, NU>([](T v) { return v; }, fx, fu, gxn, gu1, lxxn, luxn, luu, tile);
 }
 
 // ---------------------------------------------------------------------------

@@ -129,6 +129,12 @@ template <typename T, int NX, int NU> struct has_fwd_in<T, NX, NU, decltype((voi
 #ifndef ILQR_FUSE_INTEG_MASK
 #define ILQR_FUSE_INTEG_MASK 0x1f
 #endif
+#ifndef ILQR_NO_PAIR_PRODUCERS
+#define ILQR_NO_PAIR_PRODUCERS 0     // 1: never instantiate the two-points-per-lane producers (plugin builds whose generated code is scalar-only)
+#endif
+// a system whose templates can be instantiated on another scalar type (the float pair of the fused kernel's producers)
+template <typename Dyn, typename = void> struct has_rebind { static constexpr bool value = false; };
+template <typename Dyn> struct has_rebind<Dyn, std::void_t<typename Dyn::template rebind<float>>> { static constexpr bool value = true; };
 
 template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_ops(Ops<T>& o) {
     constexpr bool SMALL = all_integrators<Dyn>::value;
@@ -144,24 +150,42 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             // one workgroup = 16 trajectories (4 sweep waves + the producer waves, tiles through ~104 KB of LDS: one per
             // CU), or 4 trajectories (1 sweep wave, ~52 KB) while the batch then still fits the chip one workgroup per CU
             // (measured, fp32 fused kernel: B = 1024 35 vs 41 us, B = 2048 41 vs 41, B = 4096 73 vs 47)
+            // fp32 with an explicit integrator and a system that can be instantiated on a float pair: pair producers
+            constexpr bool CAN_PK = sizeof(T) == 4 && I != ILQR_INT_BACKWARD_EULER && has_rebind<Dyn>::value && !ILQR_NO_PAIR_PRODUCERS;
             static const bool ok = [] {
-                bool r = hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 16>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16>()) == hipSuccess;
-                r = r && hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 4>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4>()) == hipSuccess;
+                bool r = hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 16, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, false>()) == hipSuccess;
+                r = r && hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 4, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4, false>()) == hipSuccess;
+                if constexpr (CAN_PK)
+                    r = r && hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 16, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, true>()) == hipSuccess;
                 (void)hipGetLastError();
                 return r;
             }();
             (void)ok;
             static const int force = getenv("ILQR_FUSED_TPW") ? atoi(getenv("ILQR_FUSED_TPW")) : 0;   // A/B switch
             static const int small_max = getenv("ILQR_FUSED_SMALL_MAX") ? atoi(getenv("ILQR_FUSED_SMALL_MAX")) : 1024;
+            // Pair producers are built and tested (bit-identical) but OFF by default: measured 48.6 vs 48.1 us at B = 4096.
+            // The kernel is not bound by the producers' instruction count but by the sweep waves' chain (382 cycles per
+            // step, tools/fused_stamps.py), and four lone pair-producer waves deliver their first unit later (11.7 k vs
+            // 5.0 k cycles) and leave the sweep waiting more (12.2 k vs 3.7 k cycles) than eight scalar ones.
+            static const bool no_pk = getenv("ILQR_FUSED_PAIRS") == nullptr;                          // A/B switch
             const bool small = force ? force == 4 : a.B <= small_max;
-            if (small)
-                ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 4>), dim3((a.B + 3) / 4), dim3(fused_threads<T, 4>()),
-                            (fused_lds_bytes<T, 4>()), s, a);
-            else
-                ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16>()),
-                            (fused_lds_bytes<T, 16>()), s, a);
+            if (small) {
+                ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 4, false>), dim3((a.B + 3) / 4), dim3(fused_threads<T, 4, false>()),
+                            (fused_lds_bytes<T, 4, false>()), s, a);
+                return;
+            }
+            if constexpr (CAN_PK) {
+                if (!no_pk) {
+                    ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16, true>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, true>()),
+                                (fused_lds_bytes<T, 16, true>()), s, a);
+                    return;
+                }
+            }
+            ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16, false>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, false>()),
+                        (fused_lds_bytes<T, 16, false>()), s, a);
         };
     }
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
