@@ -82,46 +82,54 @@ ILQR_DEV void compiler_fence() { asm volatile("" ::: "memory"); }
 ILQR_DEV int lds_peek(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 ILQR_DEV void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
-template <typename T, typename Dyn, int INTEG, int TPW, bool PK>
-__global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused16_kernel(KArgs<T> a) {
-    constexpr int NX = Dyn::NX, NU = Dyn::NU;
+// The roles of a workgroup as functions of one struct, so that the fused kernel below and the persistent kernel
+// (persistent.hpp: the whole iteration loop of a workgroup's trajectories in one launch) run the same code.
+template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG {
+    static constexpr int NX = Dyn::NX, NU = Dyn::NU;
     static_assert(NU == 1 && NX >= 2 && NX <= 4, "the fused sweep serves the n_u = 1 DPP tile");
     static_assert(TPW == 16 || TPW == 4, "16 or 4 trajectories per workgroup");
     static_assert(!PK || (sizeof(T) == 4 && TPW == 16 && INTEG != ILQR_INT_BACKWARD_EULER), "pair producers: fp32, 16-trajectory workgroups, explicit integrators");
     using Cfg = FusedCfg<T, TPW, PK>;
-    constexpr int P = Cfg::P, RU = Cfg::RU, TL = Cfg::TILE;
-    constexpr int NSW = TPW / 4;                 // sweep waves
-    constexpr int UT = PK ? 128 : 64;            // tiles per unit (one pass of a producer wave)
-    constexpr int US = UT / TPW;                 // time steps per unit
-    constexpr int UNIT = UT * TL;                // scalars per ring slot
-    // where the tile of (step r of the unit, trajectory tl) sits in its ring slot: step-major, or -- pair producers --
-    // the two steps a lane evaluates together next to each other
-    auto tile_off = [](int r, int tl) { return PK ? ((r / 2) * TPW + tl) * 2 * TL + (r % 2) * TL : (r * TPW + tl) * TL; };
-    constexpr int R = gain_record(NX, 1);
+    static constexpr int P = Cfg::P, RU = Cfg::RU, TL = Cfg::TILE;
+    static constexpr int NSW = TPW / 4;                 // sweep waves
+    static constexpr int UT = PK ? 128 : 64;            // tiles per unit (one pass of a producer wave)
+    static constexpr int US = UT / TPW;                 // time steps per unit
+    static constexpr int UNIT = UT * TL;                // scalars per ring slot
+    static constexpr int R = gain_record(NX, 1);
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
     using V4 = typename Vec4<T>::type;
-    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
-    T* ring = reinterpret_cast<T*>(fused_lds);
-    int* ready = reinterpret_cast<int*>(fused_lds + (size_t)RU * UNIT * sizeof(T));   // [RU] unit index + 1 held by the slot
-    int* done = ready + RU;                      // [4]  units fully read, per sweep wave (NSW of them used)
-    int* s_slot = done + 4;                      // [16] slot of the trajectory's current (X, U)
-    int* s_stat = s_slot + 16;                   // [16] status word after the acceptance step (-1: beyond the batch)
+    // where the tile of (step r of the unit, trajectory tl) sits in its ring slot: step-major, or -- pair producers --
+    // the two steps a lane evaluates together next to each other
+    static ILQR_DEV constexpr int tile_off(int r, int tl) { return PK ? ((r / 2) * TPW + tl) * 2 * TL + (r % 2) * TL : (r * TPW + tl) * TL; }
+    static ILQR_DEV constexpr int step_off(int r) { return PK ? (r / 2) * TPW * 2 * TL + (r % 2) * TL : r * TPW * TL; }
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int b0 = blockIdx.x * TPW;
-    ClockProbe cp;       // (diagnostic, ILQR_CLOCK_PROBE: start / end ticks of every workgroup's thread 0 = its first sweep wave)
-    cp.start();
-    const size_t B = a.B;
-    const int N = a.N;
+    struct Lds {
+        T* ring;
+        int* ready;      // [RU] unit index + 1 held by the slot
+        int* done;       // [4]  units fully read, per sweep wave (NSW of them used)
+        int* s_slot;     // [16] slot of the trajectory's current (X, U)
+        int* s_stat;     // [16] status word after the acceptance step (-1: beyond the batch)
+    };
+    static ILQR_DEV Lds carve(unsigned char* base) {
+        Lds L;
+        L.ring = reinterpret_cast<T*>(base);
+        L.ready = reinterpret_cast<int*>(base + (size_t)RU * UNIT * sizeof(T));
+        L.done = L.ready + RU;
+        L.s_slot = L.done + 4;
+        L.s_stat = L.s_slot + 16;
+        return L;
+    }
 
-    // ---- head: acceptance step of the previous iteration's candidates (iLQR_class.py:289-307), one lane per trajectory
-    if (wave == 0) {
+    // ---- head (wave 0 only; the caller puts a workgroup barrier behind it): the acceptance step of the newest candidates
+    // (iLQR_class.py:289-307), one lane per trajectory, or just the trajectories' status and slot; clears the ring's flags.
+    // count: add the number of still-active trajectories to counters[counter_idx] (the host loop's read-back).
+    static ILQR_DEV void head(const KArgs<T>& a, const Lds& L, int b0, int lane, bool do_select, bool count) {
         bool still = false;
         if (lane < 16) {
             const int b = b0 + lane;
             int slot = 0, st = -1;
             if (lane < TPW && b < a.B) {
-                if (a.fuse_select) {
+                if (do_select) {
                     still = select_candidates(a, b, true, slot, st);
                 } else {
                     st = a.status[b];
@@ -131,25 +139,30 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
                 // stays where its accepted candidate is
                 a.cur_slot[b] = traj_active(st) ? 0 : slot;
             }
-            s_slot[lane] = slot;
-            s_stat[lane] = st;
+            L.s_slot[lane] = slot;
+            L.s_stat[lane] = st;
         } else if (lane < 16 + RU + 4) {
-            ready[lane - 16] = 0;     // ready[RU], done[4] are contiguous
+            L.ready[lane - 16] = 0;     // ready[RU], done[4] are contiguous
         }
-        if (a.fuse_select) {
+        if (do_select && count) {
             const unsigned long long m = __ballot(still);
             if (lane == 0 && m) atomicAdd(&a.counters[a.counter_idx], (int)__popcll(m));
             if (blockIdx.x == 0 && lane == 0) a.counters[(a.counter_idx + 1) % kCounterRing] = 0;
         }
     }
-    __syncthreads();
-    bool any = false;
+    static ILQR_DEV bool any_active(const Lds& L) {
+        bool any = false;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) any = any || traj_active(s_stat[q]);
-    if (!any) return;     // (uniform over the workgroup)
+        for (int q = 0; q < 16; ++q) any = any || traj_active(L.s_stat[q]);
+        return any;
+    }
 
-    const int n_units = (N + US - 1) / US;
-    if (wave < NSW) {
+    // ---- sweep role (waves 0 .. NSW-1) ------------------------------------------------------------------------------------
+    static ILQR_DEV void sweep(const KArgs<T>& a, const Lds& L, int b0, int wave, int lane, ClockProbe& cp) {
+        const size_t B = a.B;
+        const int N = a.N;
+        const int tid = threadIdx.x;
+        (void)tid;
         // ================= sweep: 4 trajectories per wave, lane (i, j) of a 16-lane row owns V_xx[i][j] ===============
         __builtin_amdgcn_s_setprio(2);
         const int l16 = lane & 15, i = l16 >> 2, j = l16 & 3;
@@ -157,9 +170,9 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
         const int gidx = b0 + tl;
         const bool valid = gidx < a.B;
         const int b = valid ? gidx : a.B - 1;
-        const int st = s_stat[tl];
+        const int st = L.s_stat[tl];
         const bool act = valid && traj_active(st);
-        const int slot = act ? s_slot[tl] : 0;
+        const int slot = act ? L.s_slot[tl] : 0;
         // terminal expansion at x_N of the accepted trajectory (iLQR_class.py:136-138), which also moves to slot 0
         const T* __restrict__ pp = a.params;
         T xN[NX];
@@ -194,7 +207,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
         using FS = FusedStep<T>;
         int goff = (N - 1) * rstride;
         // this trajectory's tile of time step r of unit k sits at unit_base(k) + r * TPW * TL: a compile-time offset per step
-        auto unit_base = [&](int k) -> const T* { return ring + (size_t)(k % RU) * UNIT + tile_off(0, tl); };
+        auto unit_base = [&](int k) -> const T* { return L.ring + (size_t)(k % RU) * UNIT + tile_off(0, tl); };
         constexpr auto step_off = [](int r) { return PK ? (r / 2) * TPW * 2 * TL + (r % 2) * TL : r * TPW * TL; };
         auto one_step = [&](const typename FS::Tile& c) {
             T Kj, kff;
@@ -212,7 +225,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
         const long long st_t0 = __builtin_readcyclecounter();
         long long st_spin = 0;
 #endif
-        while (lds_peek(&ready[0]) < 1) __builtin_amdgcn_s_sleep(1);
+        while (lds_peek(&L.ready[0]) < 1) __builtin_amdgcn_s_sleep(1);
         compiler_fence();
 #ifdef ILQR_FUSED_STAMPS
         const long long st_first = __builtin_readcyclecounter();
@@ -225,7 +238,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
             int flag = 0;
 #pragma unroll
             for (int r = 0; r < US; ++r) {
-                if (r == US - 2 && more) flag = lds_peek(&ready[(k + 1) % RU]);
+                if (r == US - 2 && more) flag = lds_peek(&L.ready[(k + 1) % RU]);
                 if (r < US - 1) {
                     FS::load(tq[(r + 1) & 1], ub + step_off(r + 1), i, j, l16);
                 } else if (more) {
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
 #endif
                     while (flag < k + 2) {
                         __builtin_amdgcn_s_sleep(1);
-                        flag = lds_peek(&ready[(k + 1) % RU]);
+                        flag = lds_peek(&L.ready[(k + 1) % RU]);
                     }
                     compiler_fence();
 #ifdef ILQR_FUSED_STAMPS
@@ -244,9 +257,9 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
                 }
                 one_step(tq[r & 1]);
             }
-            // every read of this unit has been issued (LDS serves a wave in order): its ring slot may be overwritten
+            // every read of this unit has been issued (LDS serves a wave in order): its L.ring slot may be overwritten
             compiler_fence();
-            if (lane == 0) lds_poke(&done[wave], k + 1);
+            if (lane == 0) lds_poke(&L.done[wave], k + 1);
         }
         if (rem) {      // the last, partial unit (its first tile is in tq[0] already)
             const T* ub = unit_base(n_full);
@@ -260,24 +273,30 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
         }
 #ifdef ILQR_FUSED_STAMPS
         if (a.probe && blockIdx.x == 7 && tid == 0) {
-            a.probe[5] = st_first - st_t0;                              // head of the sweep role -> first unit ready
+            a.probe[5] = st_first - st_t0;                              // head of the sweep role -> first unit L.ready
             a.probe[6] = st_spin;                                       // waiting for later units
-            a.probe[7] = __builtin_readcyclecounter() - st_first;       // first unit ready -> last step done
+            a.probe[7] = __builtin_readcyclecounter() - st_first;       // first unit L.ready -> last step L.done
         }
 #endif
         cp.stop(a.probe, 0);
         if (act && l16 == 0 && !all_pd) a.status[b] = st | ILQR_TRAJ_FLAG_NON_PD;
-    } else if constexpr (PK) {
+    }
+
+    // ---- producer role (waves NSW .. NSW+P-1; pw = the producer's index) ----------------------------------------------------
+    static ILQR_DEV void produce(const KArgs<T>& a, const Lds& L, int b0, int pw, int lane) {
+        const size_t B = a.B;
+        const int N = a.N;
+        const int n_units = (N + US - 1) / US;
+        if constexpr (PK) {
         // ================= pair producers: lane = (trajectory tl, time steps 2 r2 and 2 r2 + 1 of the unit) ===========
         using T2 = pair_f32;
         using Dyn2 = typename Dyn::template rebind<T2>;
-        const int pw = wave - NSW;
         const int tl = lane % TPW, r2 = lane / TPW;
         const int gidx = b0 + tl;
         const bool valid = gidx < a.B;
         const int b = valid ? gidx : a.B - 1;
-        const bool actb = valid && traj_active(s_stat[tl]);
-        const int slot = actb ? s_slot[tl] : 0;
+        const bool actb = valid && traj_active(L.s_stat[tl]);
+        const int slot = actb ? L.s_slot[tl] : 0;
         const bool move = actb && slot != 0;
         T pl[PL::TOTAL];
 #pragma unroll
@@ -316,15 +335,15 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
             if (k >= RU) {
                 const int need = k - RU + 1;
                 auto slowest = [&]() {
-                    int m = lds_peek(&done[0]);
+                    int m = lds_peek(&L.done[0]);
 #pragma unroll
-                    for (int q = 1; q < NSW; ++q) m = min(m, lds_peek(&done[q]));
+                    for (int q = 1; q < NSW; ++q) m = min(m, lds_peek(&L.done[q]));
                     return m;
                 };
                 while (slowest() < need) __builtin_amdgcn_s_sleep(2);
             }
             compiler_fence();
-            V4* dst = reinterpret_cast<V4*>(ring + (size_t)(k % RU) * UNIT + tile_off(2 * r2, tl));
+            V4* dst = reinterpret_cast<V4*>(L.ring + (size_t)(k % RU) * UNIT + tile_off(2 * r2, tl));
             if (ina) {
 #pragma unroll
                 for (int q = 0; q < 12; ++q) dst[q] = tile_a[q];
@@ -334,17 +353,16 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
                 for (int q = 0; q < 12; ++q) dst[TL / 4 + q] = tile_b[q];
             }
             compiler_fence();
-            if (lane == 0) lds_poke(&ready[k % RU], k + 1);
+            if (lane == 0) lds_poke(&L.ready[k % RU], k + 1);
         }
-    } else {
+        } else {
         // ================= producers: lane = (trajectory tl, time step r of the unit) ================================
-        const int pw = wave - NSW;
         const int tl = lane % TPW, r = lane / TPW;
         const int gidx = b0 + tl;
         const bool valid = gidx < a.B;
         const int b = valid ? gidx : a.B - 1;
-        const bool actb = valid && traj_active(s_stat[tl]);
-        const int slot = actb ? s_slot[tl] : 0;
+        const bool actb = valid && traj_active(L.s_stat[tl]);
+        const int slot = actb ? L.s_slot[tl] : 0;
         const bool move = actb && slot != 0;
         T p[PL::TOTAL];
 #pragma unroll
@@ -364,13 +382,13 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
             Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);
             V4 tile[12];
             tile16_pack<T, Dyn>(p, a.dt, x, u, fx, fu, tile);
-            // the ring slot is free once every sweep wave has read unit k - RU
+            // the L.ring slot is free once every sweep wave has read unit k - RU
             if (k >= RU) {
                 const int need = k - RU + 1;
                 auto slowest = [&]() {
-                    int m = lds_peek(&done[0]);
+                    int m = lds_peek(&L.done[0]);
 #pragma unroll
-                    for (int q = 1; q < NSW; ++q) m = min(m, lds_peek(&done[q]));
+                    for (int q = 1; q < NSW; ++q) m = min(m, lds_peek(&L.done[q]));
                     return m;
                 };
                 while (slowest() < need) __builtin_amdgcn_s_sleep(2);
@@ -380,14 +398,31 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused1
                 constexpr int NQ = 12 * (int)sizeof(V4) / 16;       // 16-byte pieces of the tile
                 vec_u4 w[NQ];
                 __builtin_memcpy(w, tile, sizeof(V4) * 12);
-                vec_u4* dst = reinterpret_cast<vec_u4*>(ring + (size_t)(k % RU) * UNIT + tile_off(r, tl));
+                vec_u4* dst = reinterpret_cast<vec_u4*>(L.ring + (size_t)(k % RU) * UNIT + tile_off(r, tl));
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) dst[q] = w[q];
             }
             compiler_fence();
-            if (lane == 0) lds_poke(&ready[k % RU], k + 1);
+            if (lane == 0) lds_poke(&L.ready[k % RU], k + 1);
+        }
         }
     }
+};
+
+template <typename T, typename Dyn, int INTEG, int TPW, bool PK>
+__global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) backward_fused16_kernel(KArgs<T> a) {
+    using W = FusedWG<T, Dyn, INTEG, TPW, PK>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    const typename W::Lds L = W::carve(fused_lds);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int b0 = blockIdx.x * TPW;
+    ClockProbe cp;       // (diagnostic, ILQR_CLOCK_PROBE: start / end ticks of every workgroup's thread 0 = its first sweep wave)
+    cp.start();
+    if (wave == 0) W::head(a, L, b0, lane, a.fuse_select != 0, true);
+    __syncthreads();
+    if (!W::any_active(L)) return;     // (uniform over the workgroup)
+    if (wave < W::NSW) W::sweep(a, L, b0, wave, lane, cp);
+    else W::produce(a, L, b0, wave - W::NSW, lane);
 }
 
 }  // namespace ilqr

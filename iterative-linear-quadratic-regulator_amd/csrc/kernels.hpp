@@ -720,8 +720,11 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
 // ---------------------------------------------------------------------------
 #include "fwd_in_gen.inc"
 
+// The rollout of candidate ai of trajectory b by this lane; in_range = the lane has a candidate at all.  The lanes of a
+// wave may hold any mix of (b, ai) -- forward_ring_kernel gives a wave 64 neighbouring trajectories of one alpha, the
+// persistent kernel (persistent.hpp) all candidates of a workgroup's trajectories -- as long as the whole wave calls it.
 template <typename T, typename Dyn, int INTEG>
-__global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
+ILQR_DEV void rollout_ring(const KArgs<T>& a, int b, int ai, bool in_range) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     using In = FwdIn<T, NX, NU>;
     // stores per step: the pieces of the state and of the control vector (one 16-byte store for n_x = 4 in fp32)
@@ -737,13 +740,11 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
     constexpr int RING_CAP = (sizeof(T) == 8 && INTEG == ILQR_INT_BACKWARD_EULER) ? 104 : 130;
     constexpr int PF = PF_CNT * SLOT_REGS > RING_CAP ? RING_CAP / SLOT_REGS : PF_CNT;
     static_assert(PF >= 2, "ring too shallow to be worth it");
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ai = blockIdx.y;
     // status, accepted flag and slot in one memory round trip (bitwise &: no short-circuit between the loads)
-    const int bc = b < a.B ? b : 0;
+    const int bc = in_range ? b : 0;
+    ai = in_range ? ai : 0;
     const int st_raw = a.status[bc], acc_raw = a.accepted[bc], slot_raw = a.cur_slot[bc];
-    const bool live = (b < a.B) & ((a.init_mode != 0) | (traj_active(st_raw) & (acc_raw == 0)));
-    if (a.init_mode && blockIdx.x == 0 && ai == 0 && threadIdx.x == 0) a.counters[a.counter_idx] = 0;   // the select that follows counts into it
+    const bool live = in_range & ((a.init_mode != 0) | (traj_active(st_raw) & (acc_raw == 0)));
     if (__ballot(live) == 0ull) return;
     const int bb = live ? b : 0;          // dead lanes shadow trajectory 0 and never store
     const size_t B = a.B;
@@ -861,6 +862,14 @@ __global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
         a.costs[(size_t)ai * B + b] = cost;
     }
     cp.stop(a.probe, 1);
+}
+
+template <typename T, typename Dyn, int INTEG>
+__global__ void __launch_bounds__(64) forward_ring_kernel(KArgs<T> a) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ai = blockIdx.y;
+    if (a.init_mode && blockIdx.x == 0 && ai == 0 && threadIdx.x == 0) a.counters[a.counter_idx] = 0;   // the select that follows counts into it
+    rollout_ring<T, Dyn, INTEG>(a, b, ai, b < a.B);
 }
 
 // ---------------------------------------------------------------------------
