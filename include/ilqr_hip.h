@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define ILQR_ABI_VERSION 2
+#define ILQR_ABI_VERSION 3
 
 typedef struct ilqr_solver_s* ilqr_handle;
 
@@ -85,8 +85,10 @@ enum {
 enum {
     ILQR_FLAG_KEEP_ITERATING = 1, /* throughput mode: trajectories never leave ACTIVE (no convergence /
                                      line-search break), so every iteration does the full batch's work */
-    ILQR_FLAG_NO_FUSE = 2         /* keep linearise, sweep and acceptance step as separate launches over a materialised
+    ILQR_FLAG_NO_FUSE = 2,        /* keep linearise, sweep and acceptance step as separate launches over a materialised
                                      expansion inside ilqr_iterate / ilqr_solve / ilqr_mpc_run (see ILQR_PHASE_FUSED) */
+    ILQR_FLAG_NO_PERSIST = 4      /* one launch per phase of an iteration and the host's loop around them instead of the
+                                     persistent kernel (see ILQR_PHASE_PERSIST) */
 };
 
 /*
@@ -152,7 +154,10 @@ enum {
     ILQR_PHASE_OTHER = 4,
     ILQR_PHASE_FUSED = 5, /* acceptance step + linearisation + sweep as one kernel (the default inside ilqr_iterate /
                              ilqr_solve / ilqr_mpc_run for the n_u = 1 DPP systems; ILQR_NO_FUSE=1 keeps the stages apart) */
-    ILQR_N_PHASES = 6
+    ILQR_PHASE_PERSIST = 6, /* the whole iteration loop of a workgroup's trajectories as one launch: ilqr_iterate(n) = one launch
+                               of n iterations, ilqr_solve and ilqr_mpc_run one launch each (ILQR_FLAG_NO_PERSIST keeps one
+                               fused launch + one rollout launch per iteration and the host's loop) */
+    ILQR_N_PHASES = 7
 };
 
 /* ---- library-level ------------------------------------------------------ */

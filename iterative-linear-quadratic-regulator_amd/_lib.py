@@ -29,8 +29,9 @@ TRAJ_ACTIVE, TRAJ_CONVERGED, TRAJ_LINESEARCH_FAILED, TRAJ_MAXITER = range(4)
 TRAJ_FLAG_NON_PD = 0x100
 FLAG_KEEP_ITERATING = 1
 FLAG_NO_FUSE = 2
-PHASES = ("linearize", "backward", "forward", "select", "other", "fused")
-ABI_VERSION = 2
+FLAG_NO_PERSIST = 4
+PHASES = ("linearize", "backward", "forward", "select", "other", "fused", "persist")
+ABI_VERSION = 3
 
 # every symbol include/ilqr_hip.h declares (tests check the library exports all of them)
 SYMBOLS = (

@@ -21,6 +21,9 @@ import re
 import sys
 
 GUARDED = ("forward_ring_kernel", "backward_tile16_kernel", "backward_tile16m2_kernel", "forward_mfma16_kernel")
+# functions (not kernels: the compiler's resource report has no entry for them) that hold a self-counted ring: the
+# assembly check covers them -- a spill of an in-flight register is an access to it
+GUARDED_FUNCS = ("role_rollout",)
 
 
 def parse(log_text):
@@ -70,7 +73,7 @@ def isa_violations(asm_path):
                                                   os.path.join(os.path.dirname(os.path.abspath(__file__)), "verify_ring_isa.py"))
     vri = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(vri)
-    res = vri.verify_text(open(asm_path, errors="replace").read(), GUARDED)
+    res = vri.verify_text(open(asm_path, errors="replace").read(), GUARDED + GUARDED_FUNCS)
     return [k for k, r in res.items() if r["violations"]], res, vri
 
 
@@ -88,8 +91,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 2:
         bad_isa, res, vri = isa_violations(sys.argv[2])
         n_isa = vri.report(res)
-        if len(res) != len(guarded):
-            sys.stderr.write(f"check_ring_kernels: {len(guarded)} guarded kernels in the log but {len(res)} in the assembly\n")
+        n_kern = sum(1 for k in res if not any(g in k for g in GUARDED_FUNCS))
+        if n_kern != len(guarded):
+            sys.stderr.write(f"check_ring_kernels: {len(guarded)} guarded kernels in the log but {n_kern} in the assembly\n")
             sys.exit(1)
         print(f"ring kernels: {len(guarded)} guarded, {sum(r['asm_loads'] for r in res.values())} asm loads verified, "
               f"{sum(len(r['assumptions']) for r in res.values())} store-skip branches assumed not taken, "

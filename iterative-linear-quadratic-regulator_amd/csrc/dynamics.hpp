@@ -160,6 +160,7 @@ ILQR_DEV double fast_rsqrt(double x) {
 // results are bit-identical to two scalar evaluations.  Used by the producers of backward_fused16_kernel.  The
 // parameter block stays scalar (SGPRs): SplatParams presents it as pairs.  Backward Euler (a data-dependent Newton
 // loop) has no pair form: is_scalar guards it.
+// (a bool converts to an ext vector as 0 / -1, not 0 / 1: the templates write `cond ? T(1) : T(0)`, never T(cond))
 typedef float pair_f32 __attribute__((ext_vector_type(2)));
 template <typename T> struct is_scalar { static constexpr bool value = true; };
 template <> struct is_scalar<pair_f32> { static constexpr bool value = false; };
@@ -331,8 +332,8 @@ template <typename T, int NU_> struct DoublePendulum {
         dh2[3] = -d2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            Jx[0][j] = T(j == 2);
-            Jx[1][j] = T(j == 3);
+            Jx[0][j] = (j == 2 ? T(1) : T(0));
+            Jx[1][j] = (j == 3 ? T(1) : T(0));
             Jx[2][j] = i11 * dh1[j] + i12 * dh2[j];
             Jx[3][j] = i12 * dh1[j] + i22 * dh2[j];
         }
@@ -468,7 +469,7 @@ template <typename T, typename Dyn> struct Stepper {
 #pragma unroll
         for (int i = 0; i < NX; ++i)
 #pragma unroll
-            for (int j = 0; j < NX; ++j) J[i][j] = T(i == j) - dt * Jx[i][j];
+            for (int j = 0; j < NX; ++j) J[i][j] = (i == j ? T(1) : T(0)) - dt * Jx[i][j];
         T F[NX], nrm2 = T(0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) { F[i] = xn[i] - x[i] - dt * k[i]; nrm2 += F[i] * F[i]; }
@@ -561,7 +562,7 @@ template <typename T, typename Dyn> struct Stepper {
         for (int i = 0; i < NX; ++i) {
             xs[i] = x[i] + c * kprev[i];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) Dx[i][j] = T(i == j) + c * Kxp[i][j];
+            for (int j = 0; j < NX; ++j) Dx[i][j] = (i == j ? T(1) : T(0)) + c * Kxp[i][j];
 #pragma unroll
             for (int j = 0; j < NU; ++j) Du[i][j] = c * Kup[i][j];
         }
@@ -616,7 +617,7 @@ template <typename T, typename Dyn> struct Stepper {
             for (int i = 0; i < NX; ++i) {
                 xn[i] = x[i] + k1[i] * dt;
 #pragma unroll
-                for (int j = 0; j < NX; ++j) fx[i][j] = T(i == j) + dt * fx[i][j];
+                for (int j = 0; j < NX; ++j) fx[i][j] = (i == j ? T(1) : T(0)) + dt * fx[i][j];
 #pragma unroll
                 for (int j = 0; j < NU; ++j) fu[i][j] = dt * fu[i][j];
             }
@@ -632,7 +633,7 @@ template <typename T, typename Dyn> struct Stepper {
                 for (int i = 0; i < NX; ++i) {
                     xn[i] = x[i] + dt * k2[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) fx[i][j] = T(i == j) + dt * K2x[i][j];
+                    for (int j = 0; j < NX; ++j) fx[i][j] = (i == j ? T(1) : T(0)) + dt * K2x[i][j];
 #pragma unroll
                     for (int j = 0; j < NU; ++j) fu[i][j] = dt * K2u[i][j];
                 }
@@ -669,7 +670,7 @@ template <typename T, typename Dyn> struct Stepper {
                 for (int i = 0; i < NX; ++i) {
                     xn[i] = x[i] + (dt / T(6)) * sk[i];
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) fx[i][j] = T(i == j) + (dt / T(6)) * sx[i][j];
+                    for (int j = 0; j < NX; ++j) fx[i][j] = (i == j ? T(1) : T(0)) + (dt / T(6)) * sx[i][j];
 #pragma unroll
                     for (int j = 0; j < NU; ++j) fu[i][j] = (dt / T(6)) * su[i][j];
                 }
@@ -684,7 +685,7 @@ template <typename T, typename Dyn> struct Stepper {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j) { J[i][j] = T(i == j) - dt * Jx[i][j]; rhs[i][j] = T(i == j); }
+                for (int j = 0; j < NX; ++j) { J[i][j] = (i == j ? T(1) : T(0)) - dt * Jx[i][j]; rhs[i][j] = (i == j ? T(1) : T(0)); }
 #pragma unroll
                 for (int j = 0; j < NU; ++j) rhs[i][NX + j] = dt * Ju[i][j];
             }

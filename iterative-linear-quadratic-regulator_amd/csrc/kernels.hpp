@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(64) forward_kernel(KArgs<T> a) {
 // wave may hold any mix of (b, ai) -- forward_ring_kernel gives a wave 64 neighbouring trajectories of one alpha, the
 // persistent kernel (persistent.hpp) all candidates of a workgroup's trajectories -- as long as the whole wave calls it.
 template <typename T, typename Dyn, int INTEG>
-ILQR_DEV void rollout_ring(const KArgs<T>& a, int b, int ai, bool in_range) {
+ILQR_DEV void rollout_ring(const KArgs<T>& a, int b, int ai, bool in_range, bool force_init = false) {
     constexpr int NX = Dyn::NX, NU = Dyn::NU;
     using In = FwdIn<T, NX, NU>;
     // stores per step: the pieces of the state and of the control vector (one 16-byte store for n_x = 4 in fp32)
@@ -744,14 +744,16 @@ ILQR_DEV void rollout_ring(const KArgs<T>& a, int b, int ai, bool in_range) {
     const int bc = in_range ? b : 0;
     ai = in_range ? ai : 0;
     const int st_raw = a.status[bc], acc_raw = a.accepted[bc], slot_raw = a.cur_slot[bc];
-    const bool live = in_range & ((a.init_mode != 0) | (traj_active(st_raw) & (acc_raw == 0)));
+    // force_init: the head of a solve (every trajectory, alpha = 0) whatever the argument block says -- the persistent kernel
+    // runs it with the block of its iterations
+    const bool live = in_range & ((a.init_mode != 0) | force_init | (traj_active(st_raw) & (acc_raw == 0)));
     if (__ballot(live) == 0ull) return;
     const int bb = live ? b : 0;          // dead lanes shadow trajectory 0 and never store
     const size_t B = a.B;
     const int N = a.N;
     const int slot = slot_raw;            // (a dead lane's slot only selects which valid rows it reads and discards)
     const int cslot = (slot + 1 + ai) % a.n_slots;
-    const T alpha = a.alphas[ai];
+    const T alpha = force_init ? T(0) : a.alphas[ai];
     // The parameter block is copied into registers once: the asm statements below carry "memory" clobbers
     // (they pin the order of loads and stores the vmcnt arithmetic relies on), and a clobber would otherwise
     // make hipcc reload every parameter from memory after each of them.
@@ -1255,3 +1257,4 @@ __global__ void gains_gather_k_kernel(T* denseUff, const T* gains, int B, int N,
 
 }  // namespace ilqr
 #include "backward_fused16.hpp"
+#include "persistent.hpp"

@@ -99,6 +99,9 @@ template <typename T> struct Ops {
     void (*backward)(const KArgs<T>&, hipStream_t) = nullptr;
     void (*forward[5])(const KArgs<T>&, hipStream_t) = {};
     void (*fused[5])(const KArgs<T>&, hipStream_t) = {};   // acceptance step + linearise + sweep in one launch (backward_fused16.hpp), or null
+    void (*persist[5])(const KArgs<T>&, const PArgs<T>&, hipStream_t) = {};
+    bool persist_any_batch[5] = {};   // the integrator also has the 16-trajectory form (batches beyond persist_small_max())
+    bool persist_big = false;   // the whole iteration / solve / MPC loop of a workgroup's trajectories in one launch (persistent.hpp), or null
     void (*eval)(const EvalArgs<T>&, hipStream_t) = nullptr;
     void (*mpc_advance)(const MpcArgs<T>&, hipStream_t) = nullptr;
     int n_dev_params = 0;
@@ -128,6 +131,14 @@ template <typename T, int NX, int NU> struct has_fwd_in<T, NX, NU, decltype((voi
 // Bit i set: integrator i gets the fused acceptance + linearise + sweep kernel (backward_fused16.hpp)
 #ifndef ILQR_FUSE_INTEG_MASK
 #define ILQR_FUSE_INTEG_MASK 0x1f
+#endif
+inline int persist_small_max() {
+    static const int v = getenv("ILQR_FUSED_SMALL_MAX") ? atoi(getenv("ILQR_FUSED_SMALL_MAX")) : 1024;
+    return v;
+}
+// Bit i set: integrator i gets the persistent kernel (persistent.hpp)
+#ifndef ILQR_PERSIST_INTEG_MASK
+#define ILQR_PERSIST_INTEG_MASK 0x1f
 #endif
 #ifndef ILQR_NO_PAIR_PRODUCERS
 #define ILQR_NO_PAIR_PRODUCERS 0     // 1: never instantiate the two-points-per-lane producers (plugin builds whose generated code is scalar-only)
@@ -187,6 +198,36 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16, false>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, false>()),
                         (fused_lds_bytes<T, 16, false>()), s, a);
         };
+    }
+    // The persistent kernel (persistent.hpp): fp32 only (the fp64 roles together exceed 256 VGPRs); batches <= 1024 in
+    // 4-trajectory workgroups (scalar producers), larger ones in 16-trajectory workgroups with the pair producers -- which
+    // backward Euler and generated systems do not have: those keep one launch per phase.
+    if constexpr (TILE && Dyn::NU == 1 && sizeof(T) == 4 && ((ILQR_FUSE_INTEG_MASK >> I) & 1) && has_fwd_in<T, Dyn::NX, Dyn::NU>::value &&
+                  ((ILQR_RING_INTEG_MASK >> I) & 1) && ((ILQR_PERSIST_INTEG_MASK >> I) & 1)) {
+        constexpr bool BIG = I != ILQR_INT_BACKWARD_EULER && has_rebind<Dyn>::value && !ILQR_NO_PAIR_PRODUCERS;
+        o.persist_big = o.persist_big || BIG;
+        o.persist[INTEG] = [](const KArgs<T>& a, const PArgs<T>& pa, hipStream_t s) {
+            static const bool ok = [] {
+                bool r = hipFuncSetAttribute((const void*)ilqr_persistent_kernel<T, Dyn, I, 4, false>,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4, false>()) == hipSuccess;
+                if constexpr (BIG)
+                    r = r && hipFuncSetAttribute((const void*)ilqr_persistent_kernel<T, Dyn, I, 16, true>,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, true>()) == hipSuccess;
+                (void)hipGetLastError();
+                return r;
+            }();
+            (void)ok;
+            if constexpr (BIG) {
+                if (a.B > persist_small_max()) {
+                    ILQR_LAUNCH((ilqr_persistent_kernel<T, Dyn, I, 16, true>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, true>()),
+                                (fused_lds_bytes<T, 16, true>()), s, a, pa);
+                    return;
+                }
+            }
+            ILQR_LAUNCH((ilqr_persistent_kernel<T, Dyn, I, 4, false>), dim3((a.B + 3) / 4), dim3(fused_threads<T, 4, false>()),
+                        (fused_lds_bytes<T, 4, false>()), s, a, pa);
+        };
+        o.persist_any_batch[INTEG] = BIG;
     }
     o.forward[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
         const dim3 grid((a.B + 63) / 64, a.n_pass), block(64);
@@ -900,6 +941,30 @@ template <typename T> class SolverT : public SolverBase {
                (size_t)N * B * R * sizeof(T) <= kDescriptorMax;
     }
     bool force_unfused = false;
+    // the persistent form (persistent.hpp): same conditions as the fused kernel, plus the ring rollout's 32-bit offsets
+    bool persist_ok() const {
+        static const bool off = getenv("ILQR_NO_PERSIST") != nullptr;   // A/B switch
+        const size_t bytes_x = (size_t)st.n_slots * (N + 1) * NX * B * sizeof(T);
+        return !off && !(cfg.flags & ILQR_FLAG_NO_PERSIST) && fused_ok() && ops.persist[cfg.integrator] && bytes_x <= kDescriptorMax &&
+               (B <= persist_small_max() || ops.persist_any_batch[cfg.integrator]);
+    }
+    int launch_persist(int n_iters, bool do_init, int n_mpc, const MpcArgs<T>* mpc) {
+        int rc;
+        if ((rc = flush_select())) return rc;
+        if ((rc = fix_slots(st))) return rc;
+        KArgs<T> a = kargs(st);
+        const int n = (int)trial_alphas.size();
+        a.n_pass = n; a.last_pass = 1; a.counter_idx = 0;
+        for (int i = 0; i < n; ++i) a.alphas[i] = (T)trial_alphas[i];
+        PArgs<T> pa{};
+        pa.n_iters = n_iters; pa.do_init = do_init ? 1 : 0; pa.n_mpc = n_mpc;
+        if (mpc) pa.mpc = *mpc;
+        timer.begin(ILQR_PHASE_PERSIST, stream);
+        ops.persist[cfg.integrator](a, pa, stream);
+        timer.end(stream);
+        lin_stale = true;
+        return check_launch();
+    }
     int flush_select() {
         if (!sel_pending) return ILQR_OK;
         sel_pending = false;
@@ -1037,6 +1102,7 @@ template <typename T> class SolverT : public SolverBase {
                 return ILQR_OK;
             }
         }
+        if (i < n && persist_ok()) return launch_persist(n - i, false, 0, nullptr);
         for (; i < n; ++i) {
             int rc = one_iteration(nullptr);
             if (rc) return rc;
@@ -1049,6 +1115,15 @@ template <typename T> class SolverT : public SolverBase {
     // one iteration late (so the stream never drains), and stops launching when none is.
     int run_solve_loop() {
         int rc;
+        if (persist_ok()) {
+            // one launch: every workgroup runs the head of the solve and then iterates until its own trajectories are
+            // done (or maxiter): no read-back of the active count, no surplus iterations
+            if (!have_problem) { err = "solve before set_problem"; return ILQR_ERR_STATE; }
+            if ((rc = launch_persist(cfg.maxiter, true, 0, nullptr))) return rc;
+            have_rollout = true;
+            iter_seq = 0;
+            return ILQR_OK;
+        }
         if ((rc = initial_rollout())) return rc;
         if (!loop_ev[0]) {
             ILQR_HIPCHK(hipEventCreateWithFlags(&loop_ev[0], hipEventDisableTiming));
@@ -1271,6 +1346,16 @@ template <typename T> class SolverT : public SolverBase {
             ILQR_HIPCHK(hipMalloc((void**)&mpc_cost_log, (size_t)n_steps * B * sizeof(T)));
             mpc_log_steps = n_steps;
         }
+        if (persist_ok()) {
+            // the whole receding-horizon loop on the device: a workgroup's MPC step lasts as long as ITS slowest instance
+            MpcArgs<T> m{};
+            m.B = B; m.N = N; m.plant_integ = cfg.plant_integrator; m.step = 0; m.dt = (T)cfg.dt; m.params = params;
+            m.U = st.U; m.cur_slot = st.cur_slot; m.x0 = st.x0; m.plant_x = plant_x;
+            m.u_log = mpc_u_log; m.x_log = mpc_x_log; m.cost_log = mpc_cost_log; m.cost = st.cost;
+            int rcp = launch_persist(cfg.maxiter, true, n_steps, &m);
+            if (rcp) return rcp;
+            have_rollout = true;
+        } else
         for (int k = 0; k < n_steps; ++k) {
             int rc = run_solve_loop();
             if (rc) return rc;
@@ -1334,6 +1419,8 @@ template <typename T> class SolverT : public SolverBase {
         bytes[ILQR_PHASE_OTHER] = 0;
         // the fused kernel materialises no expansion: it reads the trajectory and the candidates' costs, writes the gains
         bytes[ILQR_PHASE_FUSED] = b * s * (Nn * ((n + m) + (m * n + m)) + n) + bytes[ILQR_PHASE_SELECT];
+        // one iteration of the persistent kernel: the fused part + the rollouts
+        bytes[ILQR_PHASE_PERSIST] = bytes[ILQR_PHASE_FUSED] + bytes[ILQR_PHASE_FORWARD];
         return ILQR_OK;
     }
 };

@@ -96,8 +96,8 @@ class Inst:
         elif m.startswith("s_cbranch") or m == "s_branch":
             self.kind = "branch"
             self.target = ops.strip().split()[0]
-        elif m in ("s_endpgm", "s_endpgm_saved"):
-            self.kind = "end"
+        elif m in ("s_endpgm", "s_endpgm_saved", "s_setpc_b64"):
+            self.kind = "end"                    # (s_setpc_b64: the return of a non-kernel function, e.g. role_rollout)
 
 
 def parse_kernels(asm_text, names=GUARDED):
