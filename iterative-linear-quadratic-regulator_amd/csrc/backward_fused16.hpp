@@ -283,9 +283,11 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
     }
 
     // ---- producer role (waves NSW .. NSW+P-1; pw = the producer's index) ----------------------------------------------------
-    static ILQR_DEV void produce(const KArgs<T>& a, const Lds& L, int b0, int pw, int lane) {
+    static ILQR_DEV void produce(const KArgs<T>& a_, const Lds& L, int b0, int pw, int lane) {
+        // (the fields the unit loop reads, as locals: the persistent kernel's roles get the argument block as memory)
+        struct { int B; T dt; T* X; T* U; const T* params; } a = {a_.B, a_.dt, a_.X, a_.U, a_.params};
         const size_t B = a.B;
-        const int N = a.N;
+        const int N = a_.N;
         const int n_units = (N + US - 1) / US;
         if constexpr (PK) {
         // ================= pair producers: lane = (trajectory tl, time steps 2 r2 and 2 r2 + 1 of the unit) ===========

@@ -754,6 +754,9 @@ ILQR_DEV void rollout_ring(const KArgs<T>& a, int b, int ai, bool in_range, bool
     const int slot = slot_raw;            // (a dead lane's slot only selects which valid rows it reads and discards)
     const int cslot = (slot + 1 + ai) % a.n_slots;
     const T alpha = force_init ? T(0) : a.alphas[ai];
+    // (a local copy: when the argument block is memory -- the persistent kernel's roles -- a read of a.dt inside the step
+    // loop is a load hipcc waits for with vmcnt(0), which drains the register ring every step)
+    const T dt = a.dt;
     // The parameter block is copied into registers once: the asm statements below carry "memory" clobbers
     // (they pin the order of loads and stores the vmcnt arithmetic relies on), and a clobber would otherwise
     // make hipcc reload every parameter from memory after each of them.
@@ -824,9 +827,9 @@ ILQR_DEV void rollout_ring(const KArgs<T>& a, int b, int ai, bool in_range, bool
             buf_store_vec<T, NX>(rXc, vXc, uniform(t * stepX), x);
             buf_store_vec<T, NU>(rUc, vUc, uniform(t * stepU), u);
         }
-        cost += Cost<T, Dyn>::stage(p, a.dt, x, u);
+        cost += Cost<T, Dyn>::stage(p, dt, x, u);
         T xn[NX];
-        Stepper<T, Dyn>::step(INTEG, p, a.dt, x, u, xn);
+        Stepper<T, Dyn>::step(INTEG, p, dt, x, u, xn);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = xn[i];
     };

@@ -38,16 +38,22 @@ template <typename T, typename Dyn, int INTEG>
 __device__ __attribute__((noinline)) void role_rollout(const KArgs<T>* a, int b, int ai, bool in_range, int init) {
     rollout_ring<T, Dyn, INTEG>(*a, b, ai, in_range, init != 0);
 }
+// (The LDS pointers are carved from the workgroup's dynamic allocation INSIDE each role: handed over as function
+// arguments they would be generic pointers, and every tile read of the sweep a flat_load instead of a ds_read.)
 template <typename W, typename T>
-__device__ __attribute__((noinline)) void role_sweep(const KArgs<T>* a, const typename W::Lds* L, int b0, int wave, int lane) {
+__device__ __attribute__((noinline)) void role_sweep(const KArgs<T>* a, int b0, int wave, int lane) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    const typename W::Lds L = W::carve(fused_lds);
     ClockProbe cp;
     cp.start();
-    W::sweep(*a, *L, b0, wave, lane, cp);
+    W::sweep(*a, L, b0, wave, lane, cp);
     __builtin_amdgcn_s_setprio(0);
 }
 template <typename W, typename T>
-__device__ __attribute__((noinline)) void role_produce(const KArgs<T>* a, const typename W::Lds* L, int b0, int pw, int lane) {
-    W::produce(*a, *L, b0, pw, lane);
+__device__ __attribute__((noinline)) void role_produce(const KArgs<T>* a, int b0, int pw, int lane) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fused_lds[];
+    const typename W::Lds L = W::carve(fused_lds);
+    W::produce(*a, L, b0, pw, lane);
 }
 
 // PK: the 16-trajectory form runs the pair producers (4 sweep + 4 producer waves = 512 threads: 256 VGPRs per lane, which
@@ -66,6 +72,12 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) ilqr_persistent
     // the roles read the argument block where the dispatch put it (explicit arguments start the kernarg segment): no
     // private copy
     const KArgs<T>* ka = (const KArgs<T>*)(unsigned long long)(__attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr();
+#ifdef ILQR_PERSIST_STAMPS   // diagnostic build (tools/persist_stamps.py): cycles of workgroup 7's wave 0 per phase
+    long long ps[4] = {0, 0, 0, 0}, pt = __builtin_readcyclecounter();
+#define ILQR_PSTAMP(k) do { const long long now_ = __builtin_readcyclecounter(); ps[k] += now_ - pt; pt = now_; } while (0)
+#else
+#define ILQR_PSTAMP(k) do {} while (0)
+#endif
     const int n_outer = pa.n_mpc > 0 ? pa.n_mpc : 1;
     for (int ms = 0; ms < n_outer; ++ms) {
         if (pa.do_init) {
@@ -94,11 +106,13 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) ilqr_persistent
             drain_stores();
             __syncthreads();
             pending = false;
+            ILQR_PSTAMP(0);
             if (!W::any_active(L)) break;          // (uniform over the workgroup)
-            if (wave < W::NSW) role_sweep<W, T>(ka, &L, b0, wave, lane);
-            else role_produce<W, T>(ka, &L, b0, wave - W::NSW, lane);
+            if (wave < W::NSW) role_sweep<W, T>(ka, b0, wave, lane);
+            else role_produce<W, T>(ka, b0, wave - W::NSW, lane);
             drain_stores();
             __syncthreads();
+            ILQR_PSTAMP(1);
             // ---- all candidates of the workgroup's trajectories: lane = (trajectory, alpha) ---------------------------------
             {
                 const int lg = wave * 64 + lane;
@@ -108,6 +122,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) ilqr_persistent
             }
             drain_stores();
             __syncthreads();
+            ILQR_PSTAMP(2);
             pending = true;
         }
         if (pending) {
@@ -122,6 +137,7 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) ilqr_persistent
             drain_stores();
             __syncthreads();
         }
+        ILQR_PSTAMP(3);
         if (pa.n_mpc > 0) {
             // ---- MPC advance (run_iLQR_MPC.py:127-140): u0 = U[:, 0]; plant step; x_0 <- plant state; shift the warm start ------
             const MpcArgs<T>& m = pa.mpc;
@@ -178,6 +194,9 @@ __global__ void __launch_bounds__((fused_threads<T, TPW, PK>())) ilqr_persistent
             __syncthreads();
         }
     }
+#ifdef ILQR_PERSIST_STAMPS
+    if (a.probe && blockIdx.x == 7 && tid == 0) { a.probe[4] = ps[0]; a.probe[5] = ps[1]; a.probe[6] = ps[2]; a.probe[7] = ps[3]; }
+#endif
 }
 
 }  // namespace ilqr

@@ -1102,7 +1102,11 @@ template <typename T> class SolverT : public SolverBase {
                 return ILQR_OK;
             }
         }
-        if (i < n && persist_ok()) return launch_persist(n - i, false, 0, nullptr);
+        // (measured, fp32 c3 system, us per iteration persistent / two launches: B = 256 120 / 122, B = 1024 125 / 127,
+        // B = 4096 162 / 150 -- in the 16-trajectory form only 3 of the workgroup's 8 waves roll out and the phases of a
+        // workgroup wait for their slowest wave: the big-batch iteration keeps its two launches)
+        static const int it_max = getenv("ILQR_PERSIST_ITERATE_MAX") ? atoi(getenv("ILQR_PERSIST_ITERATE_MAX")) : persist_small_max();
+        if (i < n && B <= it_max && persist_ok()) return launch_persist(n - i, false, 0, nullptr);
         for (; i < n; ++i) {
             int rc = one_iteration(nullptr);
             if (rc) return rc;
@@ -1115,7 +1119,8 @@ template <typename T> class SolverT : public SolverBase {
     // one iteration late (so the stream never drains), and stops launching when none is.
     int run_solve_loop() {
         int rc;
-        if (persist_ok()) {
+        static const int solve_max = getenv("ILQR_PERSIST_SOLVE_MAX") ? atoi(getenv("ILQR_PERSIST_SOLVE_MAX")) : persist_small_max();
+        if (B <= solve_max && persist_ok()) {
             // one launch: every workgroup runs the head of the solve and then iterates until its own trajectories are
             // done (or maxiter): no read-back of the active count, no surplus iterations
             if (!have_problem) { err = "solve before set_problem"; return ILQR_ERR_STATE; }
