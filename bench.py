@@ -182,14 +182,16 @@ def timed_iterations(h, steps, warm=3):
     wall = (time.perf_counter() - t0) / steps
     h.timing_enable(True)
     h.timing_reset()
-    h.iterate(steps)
+    for _ in range(steps):        # (one call per iteration: a launch of the persistent kernel is then one iteration)
+        h.iterate(1)
     h.flush()
     ph = h.timing_get()
     h.timing_enable(False)
     return wall, ph
 
 
-FUSED_NAMES = {"fused": "backward_fused16_kernel", "forward": "forward_ring_kernel", "linearize": "linearize_kernel",
+FUSED_NAMES = {"persist": "ilqr_persistent_kernel (one launch = one whole iteration of the batch)",
+               "fused": "backward_fused16_kernel", "forward": "forward_ring_kernel", "linearize": "linearize_kernel",
                "backward": "backward_tile16_kernel", "select": "select_kernel"}
 C5_NAMES = {"linearize": "linearize_wave_kernel", "backward": "backward_mfma16_kernel", "forward": "forward_mfma16_kernel",
             "select": "select_kernel"}
@@ -235,41 +237,56 @@ def config_extras(ilqr_amd, _lib, problems, device, stream, steps=10):
 def mpc_extra(ilqr_amd, _lib, problems, np_dt, device, stream, B=1024, n_sim=10):
     """BASELINE config c4 at one GPU's shard, reported beside the headline (outside every timed region above): 1024
     warm-started MPC instances of the under-actuated double pendulum, N = 200, rk4 optimiser, backward_euler plant,
-    tol 1e-5, maxiter 50 (run_iLQR_UA_MPC.py:17-174), `n_sim` receding-horizon steps device-resident (ilqr_mpc_run),
-    with the step's attribution from the per-dispatch HIP events of a second run of the same steps."""
+    tol 1e-5, maxiter 50 (run_iLQR_UA_MPC.py:17-174), `n_sim` receding-horizon steps device-resident (ilqr_mpc_run).
+    Default path: ONE persistent launch for all steps (every workgroup paces its own instances).  Beside it the
+    host-looped form (ILQR_FLAG_NO_PERSIST: a step lasts until the batch's slowest instance has converged) with the
+    step's attribution from the per-dispatch HIP events."""
     p = problems.ua_double_pendulum(N=200)
     x0, U0 = problems.ua_batch(B, seed=2, restarts=False, N=200)
     sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np_dt)
-    h = sysm.make_handle(horizon=200, batch=B, n_alpha=10, n_trials=10, tol=p["tol"], maxiter=p["maxiter"],
-                         plant_integrator="backward_euler", device=device, stream=stream)
-    h.mpc_reset(x0, U0)
-    h.mpc_run(2)                       # cold start: the first solves run to maxiter; not part of the steady figure
-    t0 = time.perf_counter()
-    u, x, c = h.mpc_run(n_sim)         # returns after the logs have been copied back (synchronous)
-    wall = time.perf_counter() - t0
-    its = h.get(_lib.ITERS)
-    h.timing_enable(True)
-    h.timing_reset()
-    t0 = time.perf_counter()
-    h.mpc_run(n_sim)
-    wall_t = time.perf_counter() - t0
-    ph = h.timing_get()
-    h.timing_enable(False)
-    h.close()
+
+    def run(flags, timed_phases):
+        h = sysm.make_handle(horizon=200, batch=B, n_alpha=10, n_trials=10, tol=p["tol"], maxiter=p["maxiter"],
+                             plant_integrator="backward_euler", device=device, stream=stream, flags=flags)
+        h.mpc_reset(x0, U0)
+        h.mpc_run(2)                       # cold start: the first solves run to maxiter; not part of the steady figure
+        t0 = time.perf_counter()
+        u, x, c = h.mpc_run(n_sim)         # returns after the logs have been copied back (synchronous)
+        wall = time.perf_counter() - t0
+        its = h.get(_lib.ITERS)
+        ph = wall_t = None
+        if timed_phases:
+            h.timing_enable(True)
+            h.timing_reset()
+            t0 = time.perf_counter()
+            h.mpc_run(n_sim)
+            wall_t = time.perf_counter() - t0
+            ph = h.timing_get()
+            h.timing_enable(False)
+        h.close()
+        return wall, its, c, ph, wall_t
+
+    wall, its, c, _, _ = run(0, False)
+    out = {"instances": B, "horizon": 200, "maxiter": p["maxiter"], "steps": n_sim, "ms_per_mpc_step": 1e3 * wall / n_sim,
+           "instance_steps_per_sec": B * n_sim / wall, "iterations_last_step_mean": float(np.mean(its)),
+           "iterations_last_step_max": int(np.max(its)), "all_finite": bool(np.isfinite(c).all()),
+           "path": "persistent kernel: one launch for all steps, every workgroup (4 instances) paces its own solves"}
+    wall_l, its_l, c_l, ph, wall_t = run(_lib.FLAG_NO_PERSIST, True)
     busy_ms = sum(v[0] for v in ph.values())
     launches = {k: v[1] for k, v in ph.items() if v[1]}
     per_launch = {k: 1e3 * v[0] / v[1] for k, v in ph.items() if v[1]}
     n_iter_launch = max(ph.get("fused", (0, 0))[1], ph.get("backward", (0, 0))[1])
-    return {"instances": B, "horizon": 200, "maxiter": p["maxiter"], "steps": n_sim, "ms_per_mpc_step": 1e3 * wall / n_sim,
-            "instance_steps_per_sec": B * n_sim / wall, "iterations_last_step_mean": float(np.mean(its)),
-            "iterations_last_step_max": int(np.max(its)), "all_finite": bool(np.isfinite(c).all()),
-            "attribution": {"iteration_launches_per_step": n_iter_launch / n_sim,
-                            "kernel_us_per_launch": per_launch, "launches_per_step": {k: v / n_sim for k, v in launches.items()},
-                            "kernel_busy_ms_per_step": busy_ms / n_sim,
-                            "host_and_gaps_ms_per_step": 1e3 * wall_t / n_sim - busy_ms / n_sim,
-                            "note": "a step lasts until its slowest instance has converged: iteration launches per step x "
-                                    "(fused + rollout) + one plant step; `phases` = HIP-event time of every dispatch of a second "
-                                    "run of the same steps; 'other' = the plant step (mpc_advance_kernel)"}}
+    out["host_looped"] = {
+        "ms_per_mpc_step": 1e3 * wall_l / n_sim, "instance_steps_per_sec": B * n_sim / wall_l,
+        "same_result": bool(np.array_equal(c, c_l)),
+        "attribution": {"iteration_launches_per_step": n_iter_launch / n_sim, "kernel_us_per_launch": per_launch,
+                        "launches_per_step": {k: v / n_sim for k, v in launches.items()},
+                        "kernel_busy_ms_per_step": busy_ms / n_sim,
+                        "host_and_gaps_ms_per_step": 1e3 * wall_t / n_sim - busy_ms / n_sim,
+                        "note": "a step lasts until the batch's slowest instance has converged: iteration launches per step x (fused + "
+                                "rollout) + one plant step; HIP-event time of every dispatch of a second run of the same steps; "
+                                "'other' = the plant step (mpc_advance_kernel)"}}
+    return out
 
 
 def run_c4(args, world, rank, local_rank, ilqr_amd, _lib, problems, torch, dist):
@@ -531,6 +548,8 @@ def main():
         value = world * B * args.steps / wall
         path = ("materialised: linearize_kernel, backward_tile16_kernel, forward_ring_kernel, select_kernel (4 launches)"
                 if args.materialised else
+                "persistent: ilqr_persistent_kernel (the whole iteration of a shard of <= 1024 trajectories in one launch)"
+                if B <= int(os.environ.get("ILQR_PERSIST_ITERATE_MAX", "1024")) and args.dtype == "f32" else
                 "fused: backward_fused16_kernel (acceptance step + linearise + sweep, tiles through LDS), forward_ring_kernel (2 launches)")
         out = {
             "metric": "iLQR iterations/sec (batch=4096, T=200, n=4 m=1); backward-pass HBM GB/s",
@@ -568,22 +587,28 @@ def main():
                 # ("a fused variant must report against its own smaller byte count and say so"), and what
                 # bounds it is vector-instruction issue: every SIMD of the chip holds one sweep wave and two producer
                 # waves, a wave64 instruction occupies its SIMD for 4 cycles.
-                ms_f, n_f = phases["fused"]
+                # (a shard of <= 1024 trajectories runs the whole iteration as ONE launch of ilqr_persistent_kernel:
+                # the headline batch does not, a small --batch does)
+                pk = "persist" if phases["persist"][1] and not phases["fused"][1] else "fused"
+                kname = "ilqr_persistent_kernel" if pk == "persist" else "backward_fused16_kernel"
+                ms_f, n_f = phases[pk]
                 avg_f = ms_f / max(n_f, 1) * 1e-3
                 vi = pmc_valu(args.dtype, B, N)
-                insts = vi[0].get("backward_fused16_kernel") if vi else None
+                insts = vi[0].get(kname) if vi else None
                 peak_gips = 1024 * 2.4 / 4.0      # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
                 ach = insts / avg_f / 1e9 if insts else None
                 out["roofline"] = {
-                    "bound": "valu", "kernel": "backward_fused16_kernel (acceptance step + linearise + backward sweep; "
-                                               "no expansion in HBM)",
+                    "bound": "valu", "kernel": ("ilqr_persistent_kernel (the whole iteration in one launch; no expansion in HBM)"
+                                                if pk == "persist" else
+                                                "backward_fused16_kernel (acceptance step + linearise + backward sweep; "
+                                                "no expansion in HBM)"),
                     "achieved": ach, "peak": peak_gips, "unit": "G wave-instructions/s",
                     "frac": ach / peak_gips if ach else None,
                     "instructions_per_launch": insts, "instructions_source": vi[1] if vi else None,
-                    "traffic": tr[0].get("fused") if tr else None, "traffic_source": tr[1] if tr else None,
-                    "algorithmic_bytes_per_launch": ab["fused"], "avg_launch_us": avg_f * 1e6, "launches": n_f,
-                    "hbm_achieved_GBs_on_own_bytes": ab["fused"] / avg_f / 1e9,
-                    "hbm_frac_on_own_bytes": ab["fused"] / avg_f / 1e9 / HBM_PEAK_GBS,
+                    "traffic": tr[0].get(pk) if tr else None, "traffic_source": tr[1] if tr else None,
+                    "algorithmic_bytes_per_launch": ab[pk], "avg_launch_us": avg_f * 1e6, "launches": n_f,
+                    "hbm_achieved_GBs_on_own_bytes": ab[pk] / avg_f / 1e9,
+                    "hbm_frac_on_own_bytes": ab[pk] / avg_f / 1e9 / HBM_PEAK_GBS,
                     "note": "bound = vector-instruction issue (SQ_INSTS_VALU per launch / launch time against 1024 SIMDs x "
                             "2.4 GHz / 4 cycles); the HBM fraction on its own (small) byte count is given beside it; the "
                             "materialised sweep's HBM roofline is `roofline_materialised`"}

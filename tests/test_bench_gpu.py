@@ -28,9 +28,9 @@ def _bench(*args, timeout=300):
 
 
 def test_headline_line_small():
-    d = _bench("--steps", "4", "--warmup", "2", "--batch", "512", "--no-cpu-baseline")
+    d = _bench("--steps", "4", "--warmup", "2", "--batch", "2048", "--no-cpu-baseline")     # (> 1024: the two-launch fused path)
     assert d["unit"] == "iLQR iterations/sec" and d["n_gpus"] == 1 and d["steps"] == 4 and d["all_costs_finite"]
-    assert abs(d["value"] - 512 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-9
+    assert abs(d["value"] - 2048 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-9
     assert "fused" in d["config"]["iteration_path"]
     r = d["roofline"]
     assert r["bound"] == "valu" and r["avg_launch_us"] > 0 and r["launches"] == 4
@@ -42,9 +42,9 @@ def test_headline_line_small():
         c = d["configs"][tag]
         assert c["ms_per_iteration"] > 0 and c["kernels"], tag
     m = d["mpc_c4_shard"]
-    assert m["all_finite"] and m["attribution"]["iteration_launches_per_step"] >= 1
+    assert m["all_finite"] and m["host_looped"]["same_result"] and m["host_looped"]["attribution"]["iteration_launches_per_step"] >= 1
     s = d["solve_to_convergence"]
-    assert s["converged"] + s["linesearch_failed"] + s["maxiter"] == 512
+    assert s["converged"] + s["linesearch_failed"] + s["maxiter"] == 2048
 
 
 def test_headline_under_torch_distributed_run_one_rank():
@@ -90,6 +90,14 @@ def test_two_ranks_rehearsed_on_one_card(extra, unit, total):
         assert d["scaling"] == "weak" and "2 independent shards" in d["config"]["sharding"]
     else:
         assert d["config"].get("instances_per_gpu", d["config"].get("batch_per_gpu")) == total // 2
+
+
+def test_headline_small_shard_runs_persistent():
+    """A shard of <= 1024 trajectories: the whole iteration is one launch of ilqr_persistent_kernel, and the line says so."""
+    d = _bench("--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--no-solve-extra")
+    assert "persistent" in d["config"]["iteration_path"] and "ilqr_persistent_kernel" in d["roofline"]["kernel"]
+    assert d["roofline"]["launches"] == 3 and d["roofline"]["avg_launch_us"] > 0 and d["all_costs_finite"]
+    assert any(k.startswith("ilqr_persistent_kernel") for k in d["kernels"])
 
 
 def test_headline_materialised_switch():
