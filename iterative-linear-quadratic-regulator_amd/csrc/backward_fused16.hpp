@@ -39,20 +39,22 @@ namespace ilqr {
 // for two points against 989 for one, bit-identical values.  A unit is then 128 tiles; four producer waves (the pair
 // form needs ~200 VGPRs: 512-thread workgroups) produce as many points per pass as eight scalar ones.
 template <typename T, int TPW, bool PK> struct FusedCfg;
-template <> struct FusedCfg<float, 16, false> { static constexpr int P = 8, RU = 8, TILE = 52; };
-template <> struct FusedCfg<float, 16, true> { static constexpr int P = 4, RU = 4, TILE = 52; };
-template <> struct FusedCfg<double, 16, false> { static constexpr int P = 4, RU = 4, TILE = 52; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
-template <> struct FusedCfg<float, 4, false> { static constexpr int P = 3, RU = 4, TILE = 52; };
-template <> struct FusedCfg<double, 4, false> { static constexpr int P = 3, RU = 3, TILE = 52; };
+template <> struct FusedCfg<float, 16, false> { static constexpr int P = 8, RU = 8; };
+template <> struct FusedCfg<float, 16, true> { static constexpr int P = 4, RU = 4; };
+template <> struct FusedCfg<double, 16, false> { static constexpr int P = 4, RU = 4; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
+template <> struct FusedCfg<float, 4, false> { static constexpr int P = 3, RU = 4; };
+template <> struct FusedCfg<double, 4, false> { static constexpr int P = 3, RU = 3; };
 
-template <typename T, int TPW, bool PK> constexpr int fused_lds_bytes() {
-    return FusedCfg<T, TPW, PK>::RU * (PK ? 128 : 64) * FusedCfg<T, TPW, PK>::TILE * (int)sizeof(T) + (FusedCfg<T, TPW, PK>::RU + 4 + 32 + 4) * 4;
+// scalars between two tiles in LDS: the n_u = 1 tile (48) or the (4, 2) tile of backward_tile16m2.hpp (64), + 4 of padding
+template <int NU> constexpr int fused_tl() { return NU == 2 ? 68 : 52; }
+template <typename T, int TPW, bool PK, int NU = 1> constexpr int fused_lds_bytes() {
+    return FusedCfg<T, TPW, PK>::RU * (PK ? 128 : 64) * fused_tl<NU>() * (int)sizeof(T) + (FusedCfg<T, TPW, PK>::RU + 4 + 32 + 4) * 4;
 }
 template <typename T, int TPW, bool PK> constexpr int fused_threads() { return 64 * (TPW / 4 + FusedCfg<T, TPW, PK>::P); }
 
 // the sweep's view of a tile in LDS, and the step that consumes it
-template <typename T> struct FusedStep;
-template <> struct FusedStep<float> {
+template <typename T, int NU> struct FusedStep;
+template <> struct FusedStep<float, 1> {
     using Tile = TileQ;
     static ILQR_DEV void load(Tile& t, const float* tp, int i, int j, int l16) {
         const float4 s = *reinterpret_cast<const float4*>(tp + 4 * j);
@@ -63,18 +65,47 @@ template <> struct FusedStep<float> {
         t.lxx = tp[16 + l16];
         t.c = tp[32 + l16];
     }
-    static ILQR_DEV void step(const Tile& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj, float& kff, bool& pd) {
+    // out: the scalar this lane stores into the gain record (lanes (0, j): K[j]; the others: k)
+    static ILQR_DEV void step(const Tile& c, const LaneConst<float>& lc, int i, int j, float& V, float& vx, float& out, bool& pd) {
         RawTileQ none;            // (the refill arguments of the ring form are unused without REFILL)
         const i32x4 srd = {0, 0, 0, 0};
         const TileOffsets off = {0, 0, 0};
+        float Kj, kff;
         tile16_step_f32<false>(c, lc, V, vx, Kj, kff, pd, none, srd, off, 0);
+        out = (i == 0) ? Kj : kff;
     }
 };
-template <> struct FusedStep<double> {
+template <> struct FusedStep<double, 1> {
     using Tile = Tile16<double>;
     static ILQR_DEV void load(Tile& t, const double* tp, int i, int j, int l16) { tile16_load_lds(t, tp, i, j, l16); }
-    static ILQR_DEV void step(const Tile& c, const LaneConst<double>& lc, double& V, double& vx, double& Kj, double& kff, bool& pd) {
+    static ILQR_DEV void step(const Tile& c, const LaneConst<double>& lc, int i, int j, double& V, double& vx, double& out, bool& pd) {
+        double Kj, kff;
         tile16_step<double, false>(c, lc, 0.0, V, vx, Kj, kff, pd);
+        out = (i == 0) ? Kj : kff;
+    }
+};
+// n_x = 4, n_u = 2: the 64-scalar tile and the step of backward_tile16m2.hpp
+template <typename T> struct FusedStep<T, 2> {
+    using Tile = Tile16M2<T>;
+    using V4 = typename Vec4<T>::type;
+    static ILQR_DEV void load(Tile& t, const T* tp, int i, int j, int l16) {
+        const V4 si = *reinterpret_cast<const V4*>(tp + 4 * i);
+        const V4 sj = *reinterpret_cast<const V4*>(tp + 4 * j);
+        const V4 g0 = *reinterpret_cast<const V4*>(tp + 32 + 8 * j);
+        const V4 g1 = *reinterpret_cast<const V4*>(tp + 36 + 8 * j);
+        t.ski[0] = si.x; t.ski[1] = si.y; t.ski[2] = si.z; t.ski[3] = si.w;
+        t.skj[0] = sj.x; t.skj[1] = sj.y; t.skj[2] = sj.z; t.skj[3] = sj.w;
+        t.gj[0] = g0.x; t.gj[1] = g0.y; t.gj[2] = g0.z; t.gj[3] = g0.w;
+        t.gj[4] = g1.x; t.gj[5] = g1.y; t.gj[6] = g1.z; t.gj[7] = g1.w;
+        const T* gi = tp + 32 + 8 * i;
+        t.gi[0] = gi[0]; t.gi[1] = gi[1]; t.gi[3] = gi[3]; t.gi[4] = gi[4];
+        t.lxx = tp[16 + l16];
+    }
+    // out: lanes (0, j): K[0][j]; (1, j): K[1][j]; rows 2, 3: k[0] (j = 0) or k[1]
+    static ILQR_DEV void step(const Tile& c, const LaneConst<T>& lc, int i, int j, T& V, T& vx, T& out, bool& pd) {
+        T K0, K1, k0, k1;
+        tile16m2_step<T, false>(c, lc.m0, lc.m1, T(0), V, vx, K0, K1, k0, k1, pd);
+        out = (i == 0) ? K0 : ((i == 1) ? K1 : ((j == 0) ? k0 : k1));
     }
 };
 
@@ -86,16 +117,17 @@ ILQR_DEV void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXE
 // (persistent.hpp: the whole iteration loop of a workgroup's trajectories in one launch) run the same code.
 template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG {
     static constexpr int NX = Dyn::NX, NU = Dyn::NU;
-    static_assert(NU == 1 && NX >= 2 && NX <= 4, "the fused sweep serves the n_u = 1 DPP tile");
+    static_assert((NU == 1 && NX >= 2 && NX <= 4) || (NX == 4 && NU == 2), "the fused sweep serves the DPP tiles: n_u = 1, or (4, 2)");
     static_assert(TPW == 16 || TPW == 4, "16 or 4 trajectories per workgroup");
     static_assert(!PK || (sizeof(T) == 4 && TPW == 16 && INTEG != ILQR_INT_BACKWARD_EULER), "pair producers: fp32, 16-trajectory workgroups, explicit integrators");
     using Cfg = FusedCfg<T, TPW, PK>;
-    static constexpr int P = Cfg::P, RU = Cfg::RU, TL = Cfg::TILE;
+    static constexpr int P = Cfg::P, RU = Cfg::RU, TL = fused_tl<NU>();
+    static constexpr int NV = (NU == 2 ? kTile16M2 : kTile16) / 4;   // V4 pieces of a tile
     static constexpr int NSW = TPW / 4;                 // sweep waves
     static constexpr int UT = PK ? 128 : 64;            // tiles per unit (one pass of a producer wave)
     static constexpr int US = UT / TPW;                 // time steps per unit
     static constexpr int UNIT = UT * TL;                // scalars per ring slot
-    static constexpr int R = gain_record(NX, 1);
+    static constexpr int R = gain_record(NX, NU);
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
     using V4 = typename Vec4<T>::type;
     // where the tile of (step r of the unit, trajectory tl) sits in its ring slot: step-major, or -- pair producers --
@@ -197,24 +229,26 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
         // lanes (0, j) store K[j], lane (1, 0) stores k; fp32: the others carry an offset beyond the descriptor's range
         // and the hardware drops their store (backward_tile16_kernel)
         constexpr bool DROP = sizeof(T) == 4 || ILQR_DROP_ALL;
-        const bool storer = act && ((i == 0 && j < NX) || l16 == 4);
-        const int rec_off = (storer || !DROP) ? (int)((b * R + (i == 0 ? j : NX)) * sizeof(T)) : 0x7ffffff0;
+        // (n_u = 2: lanes (0, j), (1, j) store K[0][j], K[1][j]; lanes (2, 0), (2, 1) k[0], k[1])
+        const bool storer = act && (NU == 1 ? ((i == 0 && j < NX) || l16 == 4) : (i < 2 || (i == 2 && j < 2)));
+        const int rec_slot = NU == 1 ? (i == 0 ? j : NX) : (i < 2 ? 4 * i + j : 8 + j);
+        const int rec_off = (storer || !DROP) ? (int)((b * R + rec_slot) * sizeof(T)) : 0x7ffffff0;
         LaneConst<T> lc;
         lc.m0 = T(j == 0);
         lc.m1 = T(j == 1);
         lc.tr_byte = 4 * ((lane & 48) | (j << 2) | i);
         bool all_pd = true;
-        using FS = FusedStep<T>;
+        using FS = FusedStep<T, NU>;
         int goff = (N - 1) * rstride;
         // this trajectory's tile of time step r of unit k sits at unit_base(k) + r * TPW * TL: a compile-time offset per step
         auto unit_base = [&](int k) -> const T* { return L.ring + (size_t)(k % RU) * UNIT + tile_off(0, tl); };
         constexpr auto step_off = [](int r) { return PK ? (r / 2) * TPW * 2 * TL + (r % 2) * TL : r * TPW * TL; };
         auto one_step = [&](const typename FS::Tile& c) {
-            T Kj, kff;
+            T out;
             bool pd;
-            FS::step(c, lc, V, vx, Kj, kff, pd);
+            FS::step(c, lc, i, j, V, vx, out, pd);
             all_pd = all_pd && pd;
-            if (DROP || storer) buf_store1(rgain, rec_off, uniform(goff), (i == 0) ? Kj : kff);
+            if (DROP || storer) buf_store1(rgain, rec_off, uniform(goff), out);
             goff -= rstride;
         };
         // Two tile buffers used alternately (US is even, so the buffer of a step is a compile-time choice: no copies);
@@ -331,7 +365,7 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
             T2 gxn[NX], gu1[NU], lxxn[NX][NX], luxn[NU][NX], luu[NU][NU];
             Cost<T2, Dyn2>::grad(p, dt2, x, u, gxn, gu1);
             Cost<T2, Dyn2>::hess(p, dt2, x, u, lxxn, luxn, luu);
-            V4 tile_a[12], tile_b[12];
+            V4 tile_a[NV], tile_b[NV];
             tile16_fill<T, NX, NU>([](T2 v) { return v.x; }, fx, fu, gxn, gu1, lxxn, luxn, luu, tile_a);
             tile16_fill<T, NX, NU>([](T2 v) { return v.y; }, fx, fu, gxn, gu1, lxxn, luxn, luu, tile_b);
             if (k >= RU) {
@@ -348,11 +382,11 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
             V4* dst = reinterpret_cast<V4*>(L.ring + (size_t)(k % RU) * UNIT + tile_off(2 * r2, tl));
             if (ina) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) dst[q] = tile_a[q];
+                for (int q = 0; q < NV; ++q) dst[q] = tile_a[q];
             }
             if (inb) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) dst[TL / 4 + q] = tile_b[q];
+                for (int q = 0; q < NV; ++q) dst[TL / 4 + q] = tile_b[q];
             }
             compiler_fence();
             if (lane == 0) lds_poke(&L.ready[k % RU], k + 1);
@@ -382,7 +416,7 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
             }
             T xn[NX], fx[NX][NX], fu[NX][NU];
             Stepper<T, Dyn>::step_jac(INTEG, p, a.dt, x, u, xn, fx, fu);
-            V4 tile[12];
+            V4 tile[NV];
             tile16_pack<T, Dyn>(p, a.dt, x, u, fx, fu, tile);
             // the L.ring slot is free once every sweep wave has read unit k - RU
             if (k >= RU) {
@@ -397,9 +431,9 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
             }
             compiler_fence();
             if (inr) {
-                constexpr int NQ = 12 * (int)sizeof(V4) / 16;       // 16-byte pieces of the tile
+                constexpr int NQ = NV * (int)sizeof(V4) / 16;       // 16-byte pieces of the tile
                 vec_u4 w[NQ];
-                __builtin_memcpy(w, tile, sizeof(V4) * 12);
+                __builtin_memcpy(w, tile, sizeof(V4) * NV);
                 vec_u4* dst = reinterpret_cast<vec_u4*>(L.ring + (size_t)(k % RU) * UNIT + tile_off(r, tl));
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) dst[q] = w[q];

@@ -124,8 +124,16 @@ template <typename T, int C> ILQR_DEV void buf_store_vec(__amdgpu_buffer_rsrc_t 
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         if constexpr (PB == 16) {
+            // A packed-FP32 write of the data registers scheduled right behind a 16-byte store lands its high half before
+            // the store has read it -- one wait state later than the hazard hipcc knows and pads (gfx950;
+            // tools/micro/store_hazard2.hip, verify_ring_isa.store_pk_hazards).  The store stays a builtin (hipcc pads
+            // what it knows, e.g. an SGPR operand fresh from v_readlane: nothing inside an asm statement is padded, and a
+            // store written as asm with a spilled descriptor restored right in front of it went astray).  The wait state
+            // is an asm statement that READS the data registers: they stay live up to it, so nothing can overwrite them
+            // before it has executed, wherever the scheduler puts it.
             const u32x4 q = {w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
             __builtin_amdgcn_raw_buffer_store_b128(q, r, voff + 16 * k, soff, 0);
+            asm volatile("s_nop 0" : : "v"(q));
         } else if constexpr (PB == 8) {
             const u32x2 q = {w[2 * k], w[2 * k + 1]};
             __builtin_amdgcn_raw_buffer_store_b64(q, r, voff + 8 * k, soff, 0);

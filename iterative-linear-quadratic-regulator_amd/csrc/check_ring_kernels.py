@@ -15,6 +15,10 @@ dropped stores in round 1).  Given the compiler's assembly as a second argument,
 of the guarded kernels with the vmcnt queue simulated and rejects ANY access to the destination of an asm load that
 may still be in flight.
 
+A third check covers EVERY function of the assembly: a 16-byte buffer store whose next instruction is a packed-FP32 write of
+its data registers stores the new value in part of the lanes on gfx950 (measured, tools/micro/store_hazard.hip); hipcc pads
+that pair only for stores without an SGPR offset.  See verify_ring_isa.store_pk_hazards.
+
 usage: check_ring_kernels.py <hipcc stderr log> [<device .s>]      (exit 1 and a list on violation)
 """
 import re
@@ -77,6 +81,12 @@ def isa_violations(asm_path):
     return [k for k, r in res.items() if r["violations"]], res, vri
 
 
+def store_hazards(asm_path):
+    """(function, .s line, store, follower) for every wide buffer store directly followed by a packed-FP32 write of its data
+    registers, anywhere in the file (verify_ring_isa.store_pk_hazards)."""
+    return isa_violations(asm_path)[2].store_pk_hazards(open(asm_path, errors="replace").read())
+
+
 if __name__ == "__main__":
     # usage: check_ring_kernels.py <resource-usage log> [<device .s file>]
     ks = parse(open(sys.argv[1], errors="replace").read())
@@ -95,7 +105,13 @@ if __name__ == "__main__":
         if n_kern != len(guarded):
             sys.stderr.write(f"check_ring_kernels: {len(guarded)} guarded kernels in the log but {n_kern} in the assembly\n")
             sys.exit(1)
+        # every function of the file: a packed-FP32 write of a wide buffer store's data registers right behind the store
+        # (a gfx950 hazard hipcc does not pad; verify_ring_isa.store_pk_hazards)
+        haz = vri.store_pk_hazards(open(sys.argv[2], errors="replace").read())
+        for func, line, st, follower in haz:
+            sys.stderr.write(f"wide store followed by a packed write of its data: {func}\n    .s line {line}: {st}\n        {follower}\n")
+        n_isa += len(haz)
         print(f"ring kernels: {len(guarded)} guarded, {sum(r['asm_loads'] for r in res.values())} asm loads verified, "
               f"{sum(len(r['assumptions']) for r in res.values())} store-skip branches assumed not taken, "
-              f"{len(bad)} spilling, {n_isa} in-flight register accesses")
+              f"{len(bad)} spilling, {n_isa} in-flight register accesses / store hazards")
     sys.exit(1 if (bad or n_isa) else 0)

@@ -156,7 +156,7 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
         constexpr int TPB = TILE ? 64 : 256;
         ILQR_LAUNCH((linearize_kernel<T, Dyn, TILE, I>), dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, s, a);
     };
-    if constexpr (TILE && Dyn::NU == 1 && ((ILQR_FUSE_INTEG_MASK >> I) & 1)) {
+    if constexpr (TILE && ((ILQR_FUSE_INTEG_MASK >> I) & 1)) {
         o.fused[INTEG] = [](const KArgs<T>& a, hipStream_t s) {
             // one workgroup = 16 trajectories (4 sweep waves + the producer waves, tiles through ~104 KB of LDS: one per
             // CU), or 4 trajectories (1 sweep wave, ~52 KB) while the batch then still fits the chip one workgroup per CU
@@ -165,12 +165,12 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             constexpr bool CAN_PK = sizeof(T) == 4 && I != ILQR_INT_BACKWARD_EULER && has_rebind<Dyn>::value && !ILQR_NO_PAIR_PRODUCERS;
             static const bool ok = [] {
                 bool r = hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 16, false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, false>()) == hipSuccess;
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, false, Dyn::NU>()) == hipSuccess;
                 r = r && hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 4, false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4, false>()) == hipSuccess;
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4, false, Dyn::NU>()) == hipSuccess;
                 if constexpr (CAN_PK)
                     r = r && hipFuncSetAttribute((const void*)backward_fused16_kernel<T, Dyn, I, 16, true>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, true>()) == hipSuccess;
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, true, Dyn::NU>()) == hipSuccess;
                 (void)hipGetLastError();
                 return r;
             }();
@@ -185,34 +185,34 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             const bool small = force ? force == 4 : a.B <= small_max;
             if (small) {
                 ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 4, false>), dim3((a.B + 3) / 4), dim3(fused_threads<T, 4, false>()),
-                            (fused_lds_bytes<T, 4, false>()), s, a);
+                            (fused_lds_bytes<T, 4, false, Dyn::NU>()), s, a);
                 return;
             }
             if constexpr (CAN_PK) {
                 if (!no_pk) {
                     ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16, true>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, true>()),
-                                (fused_lds_bytes<T, 16, true>()), s, a);
+                                (fused_lds_bytes<T, 16, true, Dyn::NU>()), s, a);
                     return;
                 }
             }
             ILQR_LAUNCH((backward_fused16_kernel<T, Dyn, I, 16, false>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, false>()),
-                        (fused_lds_bytes<T, 16, false>()), s, a);
+                        (fused_lds_bytes<T, 16, false, Dyn::NU>()), s, a);
         };
     }
     // The persistent kernel (persistent.hpp): fp32 only (the fp64 roles together exceed 256 VGPRs); batches <= 1024 in
     // 4-trajectory workgroups (scalar producers), larger ones in 16-trajectory workgroups with the pair producers -- which
     // backward Euler and generated systems do not have: those keep one launch per phase.
-    if constexpr (TILE && Dyn::NU == 1 && sizeof(T) == 4 && ((ILQR_FUSE_INTEG_MASK >> I) & 1) && has_fwd_in<T, Dyn::NX, Dyn::NU>::value &&
+    if constexpr (TILE && sizeof(T) == 4 && ((ILQR_FUSE_INTEG_MASK >> I) & 1) && has_fwd_in<T, Dyn::NX, Dyn::NU>::value &&
                   ((ILQR_RING_INTEG_MASK >> I) & 1) && ((ILQR_PERSIST_INTEG_MASK >> I) & 1)) {
         constexpr bool BIG = I != ILQR_INT_BACKWARD_EULER && has_rebind<Dyn>::value && !ILQR_NO_PAIR_PRODUCERS;
         o.persist_big = o.persist_big || BIG;
         o.persist[INTEG] = [](const KArgs<T>& a, const PArgs<T>& pa, hipStream_t s) {
             static const bool ok = [] {
                 bool r = hipFuncSetAttribute((const void*)ilqr_persistent_kernel<T, Dyn, I, 4, false>,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4, false>()) == hipSuccess;
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 4, false, Dyn::NU>()) == hipSuccess;
                 if constexpr (BIG)
                     r = r && hipFuncSetAttribute((const void*)ilqr_persistent_kernel<T, Dyn, I, 16, true>,
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, true>()) == hipSuccess;
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, fused_lds_bytes<T, 16, true, Dyn::NU>()) == hipSuccess;
                 (void)hipGetLastError();
                 return r;
             }();
@@ -220,12 +220,12 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             if constexpr (BIG) {
                 if (a.B > persist_small_max()) {
                     ILQR_LAUNCH((ilqr_persistent_kernel<T, Dyn, I, 16, true>), dim3((a.B + 15) / 16), dim3(fused_threads<T, 16, true>()),
-                                (fused_lds_bytes<T, 16, true>()), s, a, pa);
+                                (fused_lds_bytes<T, 16, true, Dyn::NU>()), s, a, pa);
                     return;
                 }
             }
             ILQR_LAUNCH((ilqr_persistent_kernel<T, Dyn, I, 4, false>), dim3((a.B + 3) / 4), dim3(fused_threads<T, 4, false>()),
-                        (fused_lds_bytes<T, 4, false>()), s, a, pa);
+                        (fused_lds_bytes<T, 4, false, Dyn::NU>()), s, a, pa);
         };
         o.persist_any_batch[INTEG] = BIG;
     }

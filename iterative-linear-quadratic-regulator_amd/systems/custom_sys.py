@@ -236,6 +236,13 @@ def build_plugin(source, verbose=False):
         # Integrators whose rollout violates either are routed to the compiler-scheduled kernel; compile once more.
         bad = [k["name"] for k in crk.violations(crk.parse(r.stderr))]
         bad += [k for k in crk.isa_violations(asm)[0] if k not in bad]
+        # and no function may write a wide buffer store's data registers with a packed instruction right behind the store
+        # (a gfx950 hazard hipcc does not pad; the library's own 16-byte stores carry their wait state)
+        haz = crk.store_hazards(asm)
+        if haz:
+            shutil.rmtree(work, ignore_errors=True)
+            raise RuntimeError("wide store followed by a packed write of its data registers in this plugin build: "
+                               + "; ".join(f"{h[0]}: {h[2]} / {h[3]}" for h in haz[:4]))
         if verbose:
             print(f"plugin {tag}: ring mask {mask:#x}, rejected ring kernels: {bad}")
         if not bad:

@@ -98,3 +98,60 @@ def test_persistent_mpc(B, maxiter):
             for q in range(3):
                 assert np.array_equal(out[0][run][q], out[k][run][q]), (k, run, q)
     _same([o[2] for o in out], "state after the MPC steps")
+
+
+def _dp_batch(B, N, seed=4):
+    p = problems.double_pendulum(N=N)
+    rng = np.random.default_rng(seed)
+    x0 = np.asarray(p["x0"])[None] + 0.1 * rng.standard_normal((B, 4))
+    U0 = 0.05 * rng.standard_normal((B, 2, N))
+    return p, x0, U0
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("B", [37, 1040])
+def test_fully_actuated_double_pendulum_all_forms(dtype, B):
+    """n_x = 4, n_u = 2 (double_pendulum_sys.py): the 64-scalar tile of backward_tile16m2.hpp through the LDS ring -- fused
+    and (fp32) persistent against the materialised kernels, every bit of the state; solve, warm solve, iterate."""
+    p, x0, U0 = _dp_batch(B, 100)
+    hs = _handles(p, x0, U0, dtype, tol=p["tol"], maxiter=30)
+    for h in hs:
+        h.initial_rollout()
+        h.iterate(1)
+    _same(hs, "one iteration")
+    for h in hs:
+        h.iterate(4)
+    _same(hs, "four more in one call")
+    its = [h.solve() for h in hs]
+    for k in (1, 2):
+        assert np.array_equal(its[0][0], its[k][0]) and np.array_equal(its[0][1], its[k][1])
+    _same(hs, "solve")
+    assert ((hs[0].get(_lib.STATUS) & 0xff) != _lib.TRAJ_ACTIVE).all()
+
+
+@pytest.mark.parametrize("integrator,N", [("backward_euler", 30), ("euler", 9), ("midpoint", 64)])
+def test_fully_actuated_other_integrators(integrator, N):
+    p, x0, U0 = _dp_batch(24, N)
+    p = problems.double_pendulum(integrator=integrator, N=N)
+    for dtype in (np.float32, np.float64):
+        hs = _handles(p, x0, U0, dtype, tol=p["tol"], maxiter=6)
+        its = [h.solve() for h in hs]
+        for k in (1, 2):
+            assert np.array_equal(its[0][0], its[k][0]) and np.array_equal(its[0][1], its[k][1])
+        _same(hs, f"(4,2) {integrator} N={N} {np.dtype(dtype).name}")
+
+
+def test_fully_actuated_mpc():
+    """run_MPC_double_pendulum.py's loop, device-resident: one persistent launch against the host-looped forms."""
+    p, x0, U0 = _dp_batch(40, 40)
+    sysm = ilqr_amd.make_system(p["dynamics"], p["cost"], np.float32)
+    out = []
+    for flags in (0, _lib.FLAG_NO_PERSIST, _lib.FLAG_NO_FUSE):
+        h = sysm.make_handle(horizon=40, batch=40, n_alpha=10, n_trials=10, tol=p["tol"], maxiter=10,
+                             plant_integrator="backward_euler", flags=flags)
+        h.mpc_reset(x0, U0)
+        out.append((h.mpc_run(3), h))
+    for k in (1, 2):
+        for q in range(3):
+            assert np.array_equal(out[0][0][q], out[k][0][q]), (k, q)
+    _same([o[1] for o in out], "state after the MPC steps")
