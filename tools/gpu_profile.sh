@@ -34,6 +34,9 @@ step "small measurements"
 timeout -k 10 120 python3 tools/hbm_peak.py > $OUT/hbm_peak.json 2> /dev/null || exit 1
 timeout -k 10 120 ./tools/micro/issue_rate > $OUT/issue_rate.log || exit 1
 timeout -k 10 120 ./tools/micro/range_probe > $OUT/range_probe.log || exit 1
+# (built beforehand: for f in issue_rate range_probe store_hazard store_hazard2; do hipcc --offload-arch=gfx950 -O2 -o tools/micro/$f tools/micro/$f.hip; done)
+timeout -k 10 120 ./tools/micro/store_hazard > $OUT/store_hazard.log || exit 1
+timeout -k 10 120 ./tools/micro/store_hazard2 >> $OUT/store_hazard.log || exit 1
 timeout -k 10 300 python3 tools/f32_error.py > $OUT/f32_error.log 2>&1 || exit 1
 timeout -k 10 600 python3 tools/f32_status_parity.py --out $OUT/status_parity.json > $OUT/status_parity.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/c5_anomaly.py > $OUT/c5_anomaly.log 2>&1 || exit 1
