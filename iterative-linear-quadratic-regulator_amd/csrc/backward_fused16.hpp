@@ -84,7 +84,16 @@ template <> struct FusedStep<double, 1> {
         out = (i == 0) ? Kj : kff;
     }
 };
-// n_x = 4, n_u = 2: the 64-scalar tile and the step of backward_tile16m2.hpp
+// n_x = 4, n_u = 2, fp32: the scheduled step (gen_tile16m2_step.py) on its own view of the 64-scalar tile
+template <> struct FusedStep<float, 2> {
+    using Tile = TileQ2;
+    static ILQR_DEV void load(Tile& t, const float* tp, int i, int j, int l16) { tileq2_load_lds(t, tp, i, j, l16); }
+    static ILQR_DEV void step(const Tile& c, const LaneConst<float>& lc, int i, int j, float& V, float& vx, float& out, bool& pd) {
+        const GainSel sel = GainSel::of(i, j);      // (loop invariant: three compares outside the sweep's loop)
+        tile16m2_step_f32(c, lc, sel, V, vx, out, pd);
+    }
+};
+// n_x = 4, n_u = 2 (fp64): the 64-scalar tile and the step of backward_tile16m2.hpp
 template <typename T> struct FusedStep<T, 2> {
     using Tile = Tile16M2<T>;
     using V4 = typename Vec4<T>::type;

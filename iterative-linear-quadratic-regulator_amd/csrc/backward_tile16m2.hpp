@@ -136,6 +136,85 @@ ILQR_DEV void tile16m2_step(const Tile16M2<T>& c, T m0, T m1, T mu, T& V, T& vx,
     }
 }
 
+// ---- fp32 without regularisation: the step as a scheduled instruction stream (gen_tile16m2_step.py) ---------------------------
+// Its view of the tile: SK[j][0..3], the eight scalars of group j, and four single scalars whose QUAD holds what the lane
+// needs of row i -- a = SK[i][j] (quad: SK[i][0..3]), c = group i's scalar j (quad: f_u[i][0], f_u[i][1], l_x[i], l_ux[0][i]),
+// c2 = group i's scalar 4 + j (lane 0 of the quad: l_ux[1][i]) -- which the step reads through DPP quad broadcasts instead
+// of loading SK[i][.] and group i a second time (64 instead of 84 bytes per lane and step).
+struct TileQ2 {
+    float sj[4];
+    float g[8];
+    float a, lxx, c, c2;
+};
+// which scalar of the step a lane stores into the gain record, as wave-wide lane masks (loop invariants in SGPRs)
+struct GainSel {
+    unsigned long long i1, jn0, r23;     // lanes of row 1; lanes with j != 0; lanes of rows 2, 3
+    ILQR_DEV static GainSel of(int i, int j) {
+        GainSel s;
+        s.i1 = __ballot(i == 1);
+        s.jn0 = __ballot(j != 0);
+        s.r23 = __ballot(i >= 2);
+        return s;
+    }
+};
+#include "tile16m2_step_gen.inc"
+
+struct TileOffsetsQ2 { int vj, gj, vl, vc; };
+ILQR_DEV void tileq2_load_buf(TileQ2& t, __amdgpu_buffer_rsrc_t r, const TileOffsetsQ2& o, int soff) {
+    BufLoad<0, float>::v4(r, o.vj, soff, t.sj);
+    BufLoad<0, float>::v4(r, o.gj, soff, t.g);
+    BufLoad<4, float>::v4(r, o.gj, soff, t.g + 4);
+    t.a = BufLoad<0, float>::v1(r, o.vl, soff);
+    t.lxx = BufLoad<16, float>::v1(r, o.vl, soff);
+    t.c = BufLoad<0, float>::v1(r, o.vc, soff);
+    t.c2 = BufLoad<4, float>::v1(r, o.vc, soff);
+}
+ILQR_DEV void tileq2_load_lds(TileQ2& t, const float* tp, int i, int j, int l16) {
+    const float4 s = *reinterpret_cast<const float4*>(tp + 4 * j);
+    const float4 g0 = *reinterpret_cast<const float4*>(tp + 32 + 8 * j);
+    const float4 g1 = *reinterpret_cast<const float4*>(tp + 36 + 8 * j);
+    t.sj[0] = s.x; t.sj[1] = s.y; t.sj[2] = s.z; t.sj[3] = s.w;
+    t.g[0] = g0.x; t.g[1] = g0.y; t.g[2] = g0.z; t.g[3] = g0.w;
+    t.g[4] = g1.x; t.g[5] = g1.y; t.g[6] = g1.z; t.g[7] = g1.w;
+    t.a = tp[l16];
+    t.lxx = tp[16 + l16];
+    t.c = tp[32 + 8 * i + j];
+    t.c2 = tp[36 + 8 * i + j];
+}
+// the ring slot of this view (rules as RawTileM2)
+struct RawTileQ2 {
+    static constexpr int NLOAD = 7;
+    f32x4n sj, g0, g1;
+    float a, lxx, c, c2;
+#define ILQR_RAWTILE_Q2(OUT)                                                                 \
+    asm volatile(                                                                            \
+        "s_nop 4\n\t"                                                                        \
+        "buffer_load_dwordx4 %0, %7, %11, %12 offen\n\t"                                     \
+        "buffer_load_dwordx4 %1, %8, %11, %12 offen\n\t"                                     \
+        "buffer_load_dwordx4 %2, %8, %11, %12 offen offset:16\n\t"                           \
+        "buffer_load_dword %3, %9, %11, %12 offen\n\t"                                       \
+        "buffer_load_dword %4, %9, %11, %12 offen offset:64\n\t"                             \
+        "buffer_load_dword %5, %10, %11, %12 offen\n\t"                                      \
+        "buffer_load_dword %6, %10, %11, %12 offen offset:16"                                 \
+        : OUT(sj), OUT(g0), OUT(g1), OUT(a), OUT(lxx), OUT(c), OUT(c2)                       \
+        : "v"(o.vj), "v"(o.gj), "v"(o.vl), "v"(o.vc), "s"(srd), "s"(soff)                    \
+        : "memory")
+    template <bool FIRST> ILQR_DEV void issue(const i32x4& srd, const TileOffsetsQ2& o, int soff) {
+        if constexpr (FIRST) ILQR_RAWTILE_Q2(ILQR_OUT_FIRST);
+        else ILQR_RAWTILE_Q2(ILQR_OUT_REFILL);
+    }
+    template <int N> ILQR_DEV void wait() {
+        asm volatile("s_waitcnt vmcnt(%7)"
+                     : "+v"(sj), "+v"(g0), "+v"(g1), "+v"(a), "+v"(lxx), "+v"(c), "+v"(c2) : "i"(N) : "memory");
+    }
+    ILQR_DEV void unpack(TileQ2& t) const {
+        t.sj[0] = sj.x; t.sj[1] = sj.y; t.sj[2] = sj.z; t.sj[3] = sj.w;
+        t.g[0] = g0.x; t.g[1] = g0.y; t.g[2] = g0.z; t.g[3] = g0.w;
+        t.g[4] = g1.x; t.g[5] = g1.y; t.g[6] = g1.z; t.g[7] = g1.w;
+        t.a = a; t.lxx = lxx; t.c = c; t.c2 = c2;
+    }
+};
+
 template <typename T, bool REG>
 __global__ void __launch_bounds__(256) backward_tile16m2_kernel(KArgs<T> a) {
     constexpr int R = gain_record(4, 2);   // 12
@@ -177,7 +256,61 @@ __global__ void __launch_bounds__(256) backward_tile16m2_kernel(KArgs<T> a) {
         const T out = (i == 0) ? K0 : ((i == 1) ? K1 : ((j == 0) ? k0 : k1));
         if (storer) buf_store1(rgain, rec_off, uniform(t * rstride), out);
     };
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (sizeof(T) == 4 && !REG) {
+        // fp32, mu = 0: the scheduled step on its own view of the tile; ring as below
+        TileOffsetsQ2 oq;
+        oq.vj = off.vj;
+        oq.gj = off.gj;
+        oq.vl = (int)((b * kTile16M2 + l16) * sizeof(T));
+        oq.vc = (int)((b * kTile16M2 + 32 + 8 * i + j) * sizeof(T));
+        LaneConst<float> lc;
+        lc.m0 = m0;
+        lc.m1 = m1;
+        lc.tr_byte = 0;
+        const GainSel sel = GainSel::of(i, j);
+        auto do_step_q = [&](const TileQ2& c, int t) {
+            float out;
+            bool pd;
+            tile16m2_step_f32(c, lc, sel, V, vx, out, pd);
+            all_pd = all_pd && pd;
+            if (storer) buf_store1(rgain, rec_off, uniform(t * rstride), out);
+        };
+        constexpr int D = 8, NL = RawTileQ2::NLOAD;
+        static_assert((D - 1) * (NL + 1) <= 63, "vmcnt field");
+        int t = N - 1;
+        for (int r = N % D; r > 0; --r, --t) {
+            TileQ2 c;
+            tileq2_load_buf(c, rlin, oq, uniform(t * tstride));
+            do_step_q(c, t);
+        }
+        if (t >= 0) {
+            const i32x4 srd = make_srd(a.lin, lin_bytes);
+            RawTileQ2 ring[D];
+#pragma unroll
+            for (int u = 0; u < D; ++u) ring[u].template issue<true>(srd, oq, uniform((t - u) * tstride));
+#pragma unroll
+            for (int u = 0; u < D; ++u) {
+                ring[u].template wait<(D - 1) * NL>();
+                TileQ2 c;
+                ring[u].unpack(c);
+                do_step_q(c, t - u);
+                const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
+                ring[u].template issue<false>(srd, oq, uniform(tn * tstride));
+            }
+            for (t -= D; t >= 0; t -= D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    ring[u].template wait<(D - 1) * (NL + 1)>();
+                    TileQ2 c;
+                    ring[u].unpack(c);
+                    do_step_q(c, t - u);
+                    const int tn = (t - u - D) > 0 ? (t - u - D) : 0;
+                    ring[u].template issue<false>(srd, oq, uniform(tn * tstride));
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    } else if constexpr (sizeof(T) == 4) {
         // fp32: D tiles per lane in flight, self-counted vmcnt (see backward_tile16_kernel); every step issues exactly
         // NL loads and one store, so slot u has landed when at most (D-1)*(NL+1) younger operations are outstanding
         constexpr int D = 8, NL = RawTileM2<T>::NLOAD;

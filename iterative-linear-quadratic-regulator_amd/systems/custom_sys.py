@@ -31,7 +31,8 @@ from .system_base import System
 
 PLUGIN_ROOT = os.path.join(_lib.HERE, "_plugins")
 TEMPLATE = os.path.join(_lib.CSRC, "plugin_template.hip.in")
-_KERNEL_HEADERS = ("dynamics.hpp", "kernels.hpp", "backward_tile16.hpp", "backward_tile16m2.hpp", "kernels_wave.hpp", "backward_mfma16.hpp", "fwd_in_gen.inc",
+_KERNEL_HEADERS = ("dynamics.hpp", "kernels.hpp", "backward_tile16.hpp", "backward_tile16m2.hpp", "tile16m2_step_gen.inc", "backward_fused16.hpp",
+                   "persistent.hpp", "forward_mfma16.hpp", "kernels_wave.hpp", "backward_mfma16.hpp", "fwd_in_gen.inc",
                    "solver.hpp", "plugin_template.hip.in", "check_ring_kernels.py", "verify_ring_isa.py")
 
 
