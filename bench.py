@@ -226,6 +226,11 @@ def config_extras(ilqr_amd, _lib, problems, device, stream, steps=10):
     x0, U0 = problems.ua_batch(4096, seed=1000)
     run("c3_f64", ilqr_amd.make_system(p["dynamics"], p["cost"], np.float64), x0, U0, 200, FUSED_NAMES,
         "the headline workload in fp64")
+    # (not a BASELINE config: the reference's third system, run_MPC_double_pendulum.py -- n_u = 2 on the same fused path)
+    p = problems.double_pendulum(N=100)
+    rng = np.random.default_rng(7)
+    run("dp_4x2", ilqr_amd.make_system(p["dynamics"], p["cost"], np.float32), np.asarray(p["x0"])[None] + 0.1 * rng.standard_normal((4096, 4)),
+        np.zeros((4096, 2, 100)), 100, FUSED_NAMES, "fully actuated double pendulum n=4 m=2, N=100 rk4, batch 4096")
     p = problems.linear_quadratic()
     for B, tag in ((128, "c5_shard"), (1024, "c5")):
         x0, U0 = problems.lq_batch(B, 16, 8, 500)

@@ -360,6 +360,55 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
         // Cholesky Quu = L L', redundantly in every lane (all operands are wave-uniform); Li[c] = 1 / L[c][c]
         T L[NU][NU], Li[NU];
         bool pd = true;
+        T y[NU];
+        if constexpr (sizeof(T) == 4) {
+            // fp32 (round 3): the same factorisation and forward substitution on ROW PAIRS in packed FP32 -- rows 2p, 2p + 1
+            // of a column share one v_pk_fma_f32 (the multiplier L[cc][s] / y[s] is one half of a pair, broadcast by
+            // op_sel).  Every element still receives the same products in the same order (ascending s), the diagonal is
+            // the pair element (cc, cc) of the same recurrence: bit for bit the scalar results, in ~75 fewer vector
+            // instructions per step of a wave that is bound by its instruction count (tools/c5_issue_model.py).
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            constexpr int NP = NU / 2;
+            f2 L2[NP][NU];                       // L2[p][s] = (L[2p][s], L[2p + 1][s])
+#pragma unroll
+            for (int cc = 0; cc < NU; ++cc) {
+                f2 v2[NP];
+#pragma unroll
+                for (int pp = cc / 2; pp < NP; ++pp) {
+                    v2[pp].x = q[2 * pp >= cc ? 2 * pp : cc][cc];          // (row 2p < cc only when 2p + 1 = cc: unused half)
+                    v2[pp].y = q[2 * pp + 1][cc];
+#pragma unroll
+                    for (int s2 = 0; s2 < cc; ++s2) {
+                        const float m = (cc & 1) ? L2[cc / 2][s2].y : L2[cc / 2][s2].x;    // L[cc][s]
+                        v2[pp] = __builtin_elementwise_fma(-L2[pp][s2], f2{m, m}, v2[pp]);
+                    }
+                }
+                const float d = (cc & 1) ? v2[cc / 2].y : v2[cc / 2].x;
+                pd = pd && (d > 0.0f);
+                const float inv = fast_rsqrt(pd ? d : 1.0f);
+                Li[cc] = inv;
+#pragma unroll
+                for (int pp = cc / 2; pp < NP; ++pp) L2[pp][cc] = v2[pp] * f2{inv, inv};
+            }
+#pragma unroll
+            for (int i = 0; i < NU; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) L[i][j] = (i & 1) ? L2[i / 2][j].y : L2[i / 2][j].x;
+            all_pd = all_pd && pd;
+            ILQR_STAMP(4, Li[7]);
+            if (pd) {
+                f2 w2[NP];
+#pragma unroll
+                for (int pp = 0; pp < NP; ++pp) w2[pp] = f2{rhs[2 * pp], rhs[2 * pp + 1]};
+#pragma unroll
+                for (int s2 = 0; s2 < NU; ++s2) {          // L y = rhs, one column of L at a time (each entry: ascending s)
+                    y[s2] = ((s2 & 1) ? w2[s2 / 2].y : w2[s2 / 2].x) * Li[s2];
+#pragma unroll
+                    for (int pp = (s2 + 1) / 2; pp < NP; ++pp)
+                        w2[pp] = __builtin_elementwise_fma(-L2[pp][s2], f2{y[s2], y[s2]}, w2[pp]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int cc = 0; cc < NU; ++cc) {
             T d = q[cc][cc];
@@ -379,14 +428,16 @@ __global__ void __launch_bounds__(64) backward_mfma16_kernel(KArgs<T> a) {
         }
         all_pd = all_pd && pd;
         ILQR_STAMP(4, Li[7]);
-        T y[NU];
+        }
         if (pd) {
+            if constexpr (sizeof(T) != 4) {
 #pragma unroll
             for (int i = 0; i < NU; ++i) {             // L y = rhs
                 T v = rhs[i];
 #pragma unroll
                 for (int s = 0; s < i; ++s) v -= L[i][s] * y[s];
                 y[i] = v * Li[i];
+            }
             }
 #pragma unroll
             for (int i = NU - 1; i >= 0; --i) {        // L' z = y

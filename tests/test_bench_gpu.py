@@ -38,7 +38,7 @@ def test_headline_line_small():
     assert rm["bound"] == "hbm" and 0 < rm["frac"] < 1 and rm["launches"] == 4
     assert set(d["materialised"]["kernels"]) >= {"linearize_kernel", "backward_tile16_kernel", "forward_ring_kernel"}
     assert set(d["kernels"]) >= {"backward_fused16_kernel", "forward_ring_kernel"}
-    for tag in ("c1", "c2", "c3_f64", "c5_shard", "c5"):
+    for tag in ("c1", "c2", "c3_f64", "dp_4x2", "c5_shard", "c5"):
         c = d["configs"][tag]
         assert c["ms_per_iteration"] > 0 and c["kernels"], tag
     m = d["mpc_c4_shard"]

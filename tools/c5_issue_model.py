@@ -19,7 +19,7 @@ def find(lbl): return next(i for i,l in enumerate(S) if l.startswith(lbl))
 i6 = find(".LBB0_6:"); 
 br = next(i for i in range(i6, len(S)) if "s_cbranch_vccz .LBB0_8" in S[i])
 i8 = find(".LBB0_8:"); i10 = find(".LBB0_10:")
-end = next(i for i in range(i10, len(S)) if "s_cbranch_vccnz .LBB0_13" in S[i])
+end = next(i for i in range(i10, len(S)) if S[i].strip().startswith("s_cbranch_"))      # the loop's back edge
 body = S[i6+1:br] + S[i8+1:end+1]
 body = [l.split(";")[0].strip() for l in body]
 body = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]

@@ -85,7 +85,7 @@ for name in ("sq_c3/summary.txt", "sq_c5/summary.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "sq_counters_" + name.split("/")[0][3:] + ".txt"))
 for name in ("hbm_peak.json", "issue_rate.log", "range_probe.log", "store_hazard.log", "f32_error.log", "c5_sweep.log", "sweep_scaling.log",
-             "status_parity.json", "c5_anomaly.log", "fused_ab.log"):
+             "status_parity.json", "c5_anomaly.log", "fused_ab.log", "other_systems.log"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, name))
 for dt in ("f32", "f64", "c5", "mpc"):

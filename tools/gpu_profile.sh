@@ -43,4 +43,5 @@ timeout -k 10 300 python3 tools/c5_anomaly.py > $OUT/c5_anomaly.log 2>&1 || exit
 timeout -k 10 300 python3 tools/fused_ab.py --f64 > $OUT/fused_ab.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/c5_sweep.py > $OUT/c5_sweep.log 2>&1 || exit 1
 timeout -k 10 300 python3 tools/sweep_scaling.py > $OUT/sweep_scaling.log 2>&1 || exit 1
+timeout -k 10 300 python3 tools/other_systems.py > $OUT/other_systems.log 2>&1 || exit 1
 cat $OUT/bench_default.json; cat $OUT/bench_f64.json
