@@ -16,10 +16,13 @@ time of every MFMA / rsqrt, and the largest stalls.  (The next step's loads are 
 import re, sys
 S = open(sys.argv[1]).read().splitlines()
 def find(lbl): return next(i for i,l in enumerate(S) if l.startswith(lbl))
-i6 = find(".LBB0_6:"); 
-br = next(i for i in range(i6, len(S)) if "s_cbranch_vccz .LBB0_8" in S[i])
-i8 = find(".LBB0_8:"); i10 = find(".LBB0_10:")
-end = next(i for i in range(i10, len(S)) if S[i].strip().startswith("s_cbranch_"))      # the loop's back edge
+# the fast path of the loop: header .. the branch that skips the LU fallback (s_cbranch_vccz T) | T: .. the back edge (s_cbranch_scc);
+# the s_cbranch_vccnz in between is the not-taken side of "not positive definite"
+i6 = max(i for i, l in enumerate(S) if "Inner Loop Header" in l or "%.preheader" in l and l.startswith(".LBB0_6"))
+i6 = next(i for i, l in enumerate(S) if l.startswith(".LBB0_6:"))
+br = next(i for i in range(i6, len(S)) if "s_cbranch_vccz" in S[i])
+i8 = find(S[br].split()[1] + ":")
+end = next(i for i in range(i8, len(S)) if S[i].strip().startswith("s_cbranch_scc"))
 body = S[i6+1:br] + S[i8+1:end+1]
 body = [l.split(";")[0].strip() for l in body]
 body = [l for l in body if l and not l.startswith(".") and not l.endswith(":")]
@@ -38,17 +41,19 @@ def cls(m):
     if m.startswith("v_mfma"): return "mfma"
     if m.startswith("v_permlane"): return "perm"
     if m.startswith("ds_bpermute"): return "bperm"
+    if m.startswith("ds_read"): return "ldsr"
+    if m.startswith("ds_write"): return "ldsw"
     if m.startswith("v_"): return "valu"
     if m.startswith("s_nop"): return "nop"
     if m.startswith("s_waitcnt"): return "wait"
     return "salu"
-COST = {"valu":(4.1,8.7),"trans":(9.0,12.5),"readlane":(8.75,8.75),"mfma":(4.1,40.0),"load":(13.5,700.0),"store":(21.0,0),"wait":(0,0),"salu":(2.0,2.0),"perm":(8.0,12.0),"bperm":(8.0,120.0),"nop":(0,0)}
+COST = {"valu":(4.1,8.7),"trans":(9.0,12.5),"readlane":(8.75,8.75),"mfma":(4.1,40.0),"load":(13.5,700.0),"store":(21.0,0),"wait":(0,0),"salu":(2.0,2.0),"perm":(8.0,12.0),"bperm":(8.0,120.0),"nop":(0,0),"ldsr":(14.0,100.0),"ldsw":(14.0,0.0)}
 t=0.0; ready={}; mix={}; mf_free=0.0; stalls=[]; lg=[]
 marks=[]
 for idx,l in enumerate(body):
     m=l.split()[0]; ops=l[len(m):]; c=cls(m); mix[c]=mix.get(c,0)+1
     f=[x.strip() for x in ops.split(",")]
-    writes = c in ("valu","trans","mfma","load","readlane","perm","bperm","salu")
+    writes = c in ("valu","trans","mfma","load","readlane","perm","bperm","salu","ldsr")
     dst = regs(f[0]) if writes and f and f[0] else set()
     src=set()
     for x in (f[1:] if writes else f): src|=regs(x)
@@ -69,7 +74,7 @@ for idx,l in enumerate(body):
     iss,lat=COST[c]
     if c=="mfma": mf_free=t+32.0
     for r in dst: ready[r]=t+lat
-    if c in ("bperm","load"): lg.append(t+lat)
+    if c in ("bperm","load","ldsr"): lg.append(t+lat)
     t+=iss
     if c=="trans": marks.append((idx,t,"rsq"))
     if c=="mfma": marks.append((idx,t,"mfma"))
