@@ -97,36 +97,43 @@ __global__ void __launch_bounds__(64) linearize_wave_kernel(KArgs<T> a) {
 // slow (tools/c5_anomaly.py: the sweep is only slow right behind that linearisation, not behind the rollout).  Same
 // sums in the same order as linearize_wave_kernel: bit-identical values.
 // ---------------------------------------------------------------------------
+// Round 3: the 320 entries of Qs and Rs are staged in LDS once per 256-thread workgroup and read back as broadcast 16-byte
+// reads.  As kernel-argument-indexed constants they had been scalar loads in twenty dependent chunks (the SGPR file holds
+// ~100): one wave took 11 us for ~450 instructions whatever the batch.
 template <typename T, int NX, int NU>
-__global__ void __launch_bounds__(64) linearize_grad_dense_kernel(KArgs<T> a) {
+__global__ void __launch_bounds__(256) linearize_grad_dense_kernel(KArgs<T> a) {
     using Dyn = Linear<T, NX, NU>;
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
+    __shared__ __attribute__((aligned(16))) T sq[NX * NX + NU * NU];
+    const T* __restrict__ p = a.params;
+    for (int k = threadIdx.x; k < NX * NX + NU * NU; k += 256) sq[k] = k < NX * NX ? p[PL::QS + k] : p[PL::RS + k - NX * NX];
+    __syncthreads();
     const size_t B = a.B;
-    const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int t = (int)(idx / B);
     const int b = (int)(idx % B);
     if (t >= a.N || !traj_active(a.status[b])) return;
     const int slot = a.cur_slot[b];
-    const T* __restrict__ p = a.params;
     T x[NX], u[NU];
     vec_load<T, NX>(a.X + vec_at(B, a.N + 1, NX, slot, t, b), x);
     vec_load<T, NU>(a.U + vec_at(B, a.N, NU, slot, t, b), u);
 #pragma unroll
     for (int j = 0; j < NX; ++j) x[j] -= p[PL::XT + j];
     T g[NX + NU];
+    const T dt = a.dt;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < NX; ++j) acc += p[PL::QS + i * NX + j] * x[j];
-        g[i] = acc * a.dt;
+        for (int j = 0; j < NX; ++j) acc += sq[i * NX + j] * x[j];
+        g[i] = acc * dt;
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {
         T acc = T(0);
 #pragma unroll
-        for (int j = 0; j < NU; ++j) acc += p[PL::RS + i * NU + j] * u[j];
-        g[NX + i] = acc * a.dt;
+        for (int j = 0; j < NU; ++j) acc += sq[NX * NX + i * NU + j] * u[j];
+        g[NX + i] = acc * dt;
     }
     vec_store<T, NX + NU>(a.lin + ((size_t)t * B + b) * (NX + NU), g);
 }

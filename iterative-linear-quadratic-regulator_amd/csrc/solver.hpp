@@ -199,7 +199,8 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
                         (fused_lds_bytes<T, 16, false, Dyn::NU>()), s, a);
         };
     }
-    // The persistent kernel (persistent.hpp): fp32 only (the fp64 roles together exceed 256 VGPRs); batches <= 1024 in
+    // The persistent kernel (persistent.hpp): fp32 only (tried for fp64 in the 4-trajectory form: as a noinline role the fp64
+    // RK4 / backward-Euler rollout spills registers of its self-counted load ring, which the build rejects); batches <= 1024 in
     // 4-trajectory workgroups (scalar producers), larger ones in 16-trajectory workgroups with the pair producers -- which
     // backward Euler and generated systems do not have: those keep one launch per phase.
     if constexpr (TILE && sizeof(T) == 4 && ((ILQR_FUSE_INTEG_MASK >> I) & 1) && has_fwd_in<T, Dyn::NX, Dyn::NU>::value &&
@@ -337,7 +338,7 @@ template <typename T, int NX, int NU> Ops<T> make_ops_wave() {
                 w.t_first = a.N - 1;
                 LaunchEvents le = launch_events();      // (the phase timer's event pair spans both launches)
                 launch_events() = LaunchEvents{le.a, nullptr};
-                ILQR_LAUNCH((linearize_grad_dense_kernel<T, NX, NU>), dim3((unsigned)(((size_t)a.B * a.N + 63) / 64)), dim3(64), 0, s, a);
+                ILQR_LAUNCH((linearize_grad_dense_kernel<T, NX, NU>), dim3((unsigned)(((size_t)a.B * a.N + 255) / 256)), dim3(256), 0, s, a);
                 launch_events() = LaunchEvents{nullptr, le.b};
                 ILQR_LAUNCH((linearize_wave_kernel<T, NX, NU>), dim3((unsigned)((size_t)a.B * 2)), dim3(64), 0, s, w);
                 return;
