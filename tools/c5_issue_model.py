@@ -18,7 +18,6 @@ S = open(sys.argv[1]).read().splitlines()
 def find(lbl): return next(i for i,l in enumerate(S) if l.startswith(lbl))
 # the fast path of the loop: header .. the branch that skips the LU fallback (s_cbranch_vccz T) | T: .. the back edge (s_cbranch_scc);
 # the s_cbranch_vccnz in between is the not-taken side of "not positive definite"
-i6 = max(i for i, l in enumerate(S) if "Inner Loop Header" in l or "%.preheader" in l and l.startswith(".LBB0_6"))
 i6 = next(i for i, l in enumerate(S) if l.startswith(".LBB0_6:"))
 br = next(i for i in range(i6, len(S)) if "s_cbranch_vccz" in S[i])
 i8 = find(S[br].split()[1] + ":")
