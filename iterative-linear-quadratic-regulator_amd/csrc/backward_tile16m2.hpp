@@ -138,13 +138,13 @@ ILQR_DEV void tile16m2_step(const Tile16M2<T>& c, T m0, T m1, T mu, T& V, T& vx,
 
 // ---- fp32 without regularisation: the step as a scheduled instruction stream (gen_tile16m2_step.py) ---------------------------
 // Its view of the tile: SK[j][0..3], the eight scalars of group j, and four single scalars whose QUAD holds what the lane
-// needs of row i -- a = SK[i][j] (quad: SK[i][0..3]), c = group i's scalar j (quad: f_u[i][0], f_u[i][1], l_x[i], l_ux[0][i]),
-// c2 = group i's scalar 4 + j (lane 0 of the quad: l_ux[1][i]) -- which the step reads through DPP quad broadcasts instead
-// of loading SK[i][.] and group i a second time (64 instead of 84 bytes per lane and step).
+// needs of row i -- a = SK[i][j] (quad: SK[i][0..3]), c = group i's scalar j (quad: f_u[i][0], f_u[i][1], ...) -- which the step
+// reads through DPP quad broadcasts instead of loading SK[i][.] and group i a second time (60 instead of 84 bytes per lane
+// and step); Q_ux reaches its row form (lane (i, j): Q_ux[c][i]) by four masked quad broadcasts of the column form.
 struct TileQ2 {
     float sj[4];
     float g[8];
-    float a, lxx, c, c2;
+    float a, lxx, c;
 };
 // which scalar of the step a lane stores into the gain record, as wave-wide lane masks (loop invariants in SGPRs)
 struct GainSel {
@@ -167,7 +167,6 @@ ILQR_DEV void tileq2_load_buf(TileQ2& t, __amdgpu_buffer_rsrc_t r, const TileOff
     t.a = BufLoad<0, float>::v1(r, o.vl, soff);
     t.lxx = BufLoad<16, float>::v1(r, o.vl, soff);
     t.c = BufLoad<0, float>::v1(r, o.vc, soff);
-    t.c2 = BufLoad<4, float>::v1(r, o.vc, soff);
 }
 ILQR_DEV void tileq2_load_lds(TileQ2& t, const float* tp, int i, int j, int l16) {
     const float4 s = *reinterpret_cast<const float4*>(tp + 4 * j);
@@ -179,24 +178,22 @@ ILQR_DEV void tileq2_load_lds(TileQ2& t, const float* tp, int i, int j, int l16)
     t.a = tp[l16];
     t.lxx = tp[16 + l16];
     t.c = tp[32 + 8 * i + j];
-    t.c2 = tp[36 + 8 * i + j];
 }
 // the ring slot of this view (rules as RawTileM2)
 struct RawTileQ2 {
-    static constexpr int NLOAD = 7;
+    static constexpr int NLOAD = 6;
     f32x4n sj, g0, g1;
-    float a, lxx, c, c2;
+    float a, lxx, c;
 #define ILQR_RAWTILE_Q2(OUT)                                                                 \
     asm volatile(                                                                            \
         "s_nop 4\n\t"                                                                        \
-        "buffer_load_dwordx4 %0, %7, %11, %12 offen\n\t"                                     \
-        "buffer_load_dwordx4 %1, %8, %11, %12 offen\n\t"                                     \
-        "buffer_load_dwordx4 %2, %8, %11, %12 offen offset:16\n\t"                           \
-        "buffer_load_dword %3, %9, %11, %12 offen\n\t"                                       \
-        "buffer_load_dword %4, %9, %11, %12 offen offset:64\n\t"                             \
-        "buffer_load_dword %5, %10, %11, %12 offen\n\t"                                      \
-        "buffer_load_dword %6, %10, %11, %12 offen offset:16"                                 \
-        : OUT(sj), OUT(g0), OUT(g1), OUT(a), OUT(lxx), OUT(c), OUT(c2)                       \
+        "buffer_load_dwordx4 %0, %6, %10, %11 offen\n\t"                                     \
+        "buffer_load_dwordx4 %1, %7, %10, %11 offen\n\t"                                     \
+        "buffer_load_dwordx4 %2, %7, %10, %11 offen offset:16\n\t"                           \
+        "buffer_load_dword %3, %8, %10, %11 offen\n\t"                                       \
+        "buffer_load_dword %4, %8, %10, %11 offen offset:64\n\t"                             \
+        "buffer_load_dword %5, %9, %10, %11 offen"                                            \
+        : OUT(sj), OUT(g0), OUT(g1), OUT(a), OUT(lxx), OUT(c)                                \
         : "v"(o.vj), "v"(o.gj), "v"(o.vl), "v"(o.vc), "s"(srd), "s"(soff)                    \
         : "memory")
     template <bool FIRST> ILQR_DEV void issue(const i32x4& srd, const TileOffsetsQ2& o, int soff) {
@@ -204,14 +201,14 @@ struct RawTileQ2 {
         else ILQR_RAWTILE_Q2(ILQR_OUT_REFILL);
     }
     template <int N> ILQR_DEV void wait() {
-        asm volatile("s_waitcnt vmcnt(%7)"
-                     : "+v"(sj), "+v"(g0), "+v"(g1), "+v"(a), "+v"(lxx), "+v"(c), "+v"(c2) : "i"(N) : "memory");
+        asm volatile("s_waitcnt vmcnt(%6)"
+                     : "+v"(sj), "+v"(g0), "+v"(g1), "+v"(a), "+v"(lxx), "+v"(c) : "i"(N) : "memory");
     }
     ILQR_DEV void unpack(TileQ2& t) const {
         t.sj[0] = sj.x; t.sj[1] = sj.y; t.sj[2] = sj.z; t.sj[3] = sj.w;
         t.g[0] = g0.x; t.g[1] = g0.y; t.g[2] = g0.z; t.g[3] = g0.w;
         t.g[4] = g1.x; t.g[5] = g1.y; t.g[6] = g1.z; t.g[7] = g1.w;
-        t.a = a; t.lxx = lxx; t.c = c; t.c2 = c2;
+        t.a = a; t.lxx = lxx; t.c = c;
     }
 };
 

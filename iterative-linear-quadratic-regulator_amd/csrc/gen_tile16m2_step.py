@@ -21,7 +21,7 @@ QSW = "quad_perm:[1,0,3,2]"
 ROR = [None, "row_ror:12", "row_ror:8", "row_ror:4"]       # rows i+1, i+2, i+3
 
 # inputs of the step: the carried state, the tile, the lane masks
-INPUTS = ["V", "vx", "a", "c", "c2", "sj0", "sj1", "sj2", "sj3", "fu0j", "fu1j", "lxj", "lux0j", "lux1j", "e0", "e1", "e2",
+INPUTS = ["V", "vx", "a", "c", "sj0", "sj1", "sj2", "sj3", "fu0j", "fu1j", "lxj", "lux0j", "lux1j", "e0", "e1", "e2",
           "lxx", "m0", "m1", "mk_i1", "mk_j", "mk_r23"]
 SGPR_INPUTS = {"mk_i1", "mk_j", "mk_r23"}
 TILE_ONLY = set(INPUTS) - {"V", "vx"}
@@ -36,8 +36,6 @@ def ins(text, dst, plain=(), dpp=(), acc=False, kind="valu"):
 # ---- SK[i][1..3] and l_ux[.][i] broadcast out of the quad (tile only) -------------------------------------------------------
 for d in (1, 2, 3):
     ins(f"v_mov_b32_dpp {{si{d}}}, {{a}} {QB[d]}{DPP}", f"si{d}", dpp=["a"])
-ins(f"v_mov_b32_dpp {{Qi0}}, {{c}} {QB[3]}{DPP}", "Qi0", dpp=["c"])         # Q_ux[0][i] (row form) = l_ux[0][i] + ...
-ins(f"v_mov_b32_dpp {{Qi1}}, {{c2}} {QB[0]}{DPP}", "Qi1", dpp=["c2"])       # Q_ux[1][i]
 # ---- A: P = f_x' V_xx, then Q_xx = l_xx + P f_x -------------------------------------------------------------------------------
 ins(f"v_mul_f32_dpp {{P}}, {{a}}, {{V}} {QB[0]}{DPP}", "P", plain=["V"], dpp=["a"])
 for d in (1, 2, 3):
@@ -53,14 +51,12 @@ for cc in (0, 1):
     ins(f"v_fma_f32 {{Qux{cc}}}, {{sj0}}, {{pv{cc}}}, {{lux{cc}j}}", f"Qux{cc}", plain=["sj0", f"pv{cc}", f"lux{cc}j"])
     for d in (1, 2, 3):
         ins(f"v_fmac_f32_dpp {{Qux{cc}}}, {{pv{cc}}}, {{sj{d}}} {QP[d]}{DPP}", f"Qux{cc}", plain=[f"sj{d}"], dpp=[f"pv{cc}"], acc=True)
-# ---- R_c: the same in row form (V_xx symmetric): pr_c[i] = sum_k f_u[k][c] V[i][k], Q_ux[c][i] += (f_x' pr_c)[i] -----------------
+# ---- Q_ux in row form (lane (i, j) needs Q_ux[c][i] for the value update): the column form's lane i of quad i, broadcast
+# inside each quad by four masked DPP moves (bank_mask = one quad of every 16-lane row; the other quads keep what they have).
+# (Until round 3 the row form was a second contraction chain through V_xx's symmetry: 16 instructions for these 8.)
 for cc in (0, 1):
-    ins(f"v_mul_f32 {{pr{cc}}}, {{fu{cc}j}}, {{V}}", f"pr{cc}", plain=[f"fu{cc}j", "V"])
-    ins(f"v_add_f32_dpp {{tr{cc}}}, {{pr{cc}}}, {{pr{cc}}} {QSW}{DPP}", f"tr{cc}", plain=[f"pr{cc}"], dpp=[f"pr{cc}"])
-    ins(f"v_add_f32_dpp {{ps{cc}}}, {{tr{cc}}}, {{tr{cc}}} {QP[2]}{DPP}", f"ps{cc}", plain=[f"tr{cc}"], dpp=[f"tr{cc}"])
-    ins(f"v_fmac_f32_dpp {{Qi{cc}}}, {{a}}, {{ps{cc}}} {QB[0]}{DPP}", f"Qi{cc}", plain=[f"ps{cc}"], dpp=["a"], acc=True)
-    for d in (1, 2, 3):
-        ins(f"v_fmac_f32_dpp {{Qi{cc}}}, {{ps{cc}}}, {{si{d}}} {ROR[d]}{DPP}", f"Qi{cc}", plain=[f"si{d}"], dpp=[f"ps{cc}"], acc=True)
+    for k in range(4):
+        ins(f"v_mov_b32_dpp {{Qi{cc}}}, {{Qux{cc}}} {QB[k]} row_mask:0xf bank_mask:{1 << k:#x}", f"Qi{cc}", dpp=[f"Qux{cc}"], acc=(k > 0))
 # ---- C: Q_x[j] = l_x[j] + (f_x' V_x)[j] -------------------------------------------------------------------------------------------
 ins("v_fma_f32 {qx}, {sj0}, {vx}, {lxj}", "qx", plain=["sj0", "vx", "lxj"])
 for d in (1, 2, 3):
@@ -203,7 +199,7 @@ for x in I:
     if x["dst"] not in temps and x["dst"] not in ("outv",):
         temps.append(x["dst"])
 w("    float " + ", ".join(temps) + ";")
-cexpr = {"V": "V", "vx": "vx", "a": "tq.a", "c": "tq.c", "c2": "tq.c2", "sj0": "tq.sj[0]", "sj1": "tq.sj[1]", "sj2": "tq.sj[2]",
+cexpr = {"V": "V", "vx": "vx", "a": "tq.a", "c": "tq.c", "sj0": "tq.sj[0]", "sj1": "tq.sj[1]", "sj2": "tq.sj[2]",
          "sj3": "tq.sj[3]", "fu0j": "tq.g[0]", "fu1j": "tq.g[1]", "lxj": "tq.g[2]", "lux0j": "tq.g[3]", "lux1j": "tq.g[4]",
          "e0": "tq.g[5]", "e1": "tq.g[6]", "e2": "tq.g[7]", "lxx": "tq.lxx", "m0": "lc.m0", "m1": "lc.m1",
          "mk_i1": "sel.i1", "mk_j": "sel.jn0", "mk_r23": "sel.r23"}
