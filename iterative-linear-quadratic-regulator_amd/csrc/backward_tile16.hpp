@@ -485,21 +485,21 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
 }
 
 // ---- fp32 step with a hand-ordered instruction stream ---------------------------------------------------
-// The chains of a step -- (A) P -> Q_xx, (B) pu -> Q_ux, (R) the same in row form, (C) Q_x, (C2) Q_u,
+// The chains of a step -- (A) P -> Q_xx, (B) pu -> Q_ux, (C) Q_x, (C2) Q_u,
 // (Q) Q_uu -> 1/Q_uu -- are independent until the gain.  A lone wave (the batch puts one wave on each SIMD) issues
 // an independent VALU instruction every ~5.4 cycles but a dependent one only every ~8.8, a dependent DPP read
 // needs two more wait states, and v_rcp_f32 costs 9 (12.5 dependent) -- tools/micro/issue_rate.hip.  hipcc's
-// order left the sweep at ~6.5 cycles/instruction; here the 37 instructions up to the reciprocal are volatile asm
+// order left the sweep at ~6.5 cycles/instruction; here the 33 instructions up to the reciprocal are volatile asm
 // statements (never reordered among themselves) written round-robin over the chains, so that every operand was
 // produced >= 3 instructions earlier: no s_nop, no dependent-issue bubble.  Q_uu is finished EARLY (27) and its
 // reciprocal issued at 31, so the transcendental's latency hides under the last four contraction terms instead of
 // heading the serial tail; the tail left to hipcc is K, k, V_xx, V_x: two dependent instructions deep.
 //
-// Chain R computes Q_ux a second time in ROW form (lane (i, j) holds Q_ux[i]) instead of transposing the column
-// form through the LDS crossbar at the end of the step (ds_bpermute + lgkmcnt wait sat on the critical path: ~68
-// cycles).  Row form needs pu[i] = sum_k f_u[k] V_xx[k][i] along the ROW, i.e. it reads V_xx[i][k] for V_xx[k][i]:
-// V_xx is symmetric up to the rounding of its own update, so the two forms agree to an ulp-sized perturbation of
-// V_xx (the reference does not symmetrise either).
+// Q_ux in ROW form (lane (i, j) holds Q_ux[i], for the value update) is taken from the column form -- lane i of quad i --
+// by four masked DPP quad broadcasts (bank_mask: one quad of every 16-lane row per move) that sit in the slots where the
+// tail used to wait for 1 / Q_uu.  (Rounds 1-2 computed it a second time as a contraction chain through V_xx's symmetry,
+// 8 instructions instead of 4 and an ulp-sized deviation from the transposed value; before that a ds_bpermute + lgkmcnt
+// wait sat on the critical path: ~68 cycles.)
 //
 // 1/Q_uu keeps its Newton step (without it the fp32 solve parts from the fp32 oracle's alpha sequence at iterations
 // where the cost still moves by 2e-3, against 2e-4 with it -- tests/test_gpu_fullshape.py), but as instructions 34
@@ -522,7 +522,7 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
 template <bool REFILL>
 ILQR_DEV void tile16_step_f32(const TileQ& c, const LaneConst<float>& lc, float& V, float& vx, float& Kj, float& kff,
                               bool& pd, RawTileQ& prev, const i32x4& srd, const TileOffsets& off, int soff) {
-    float P, pu, pr, qx, qu, quu, Qxx, Qux, Quxi, t, t2, inv, si1, si2, si3;
+    float P, pu, qx, qu, quu, Qxx, Qux, Quxi, t, t2, inv, si1, si2, si3;
 #define DPPT " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define DPPE " row_mask:0xf bank_mask:0xf bound_ctrl:1"
     // SK[i][0] and f_u[i] reach their (single-move) consumers 1, 2 and 17 as DPP broadcasts of a / c; SK[i][1..3] and
@@ -532,66 +532,62 @@ ILQR_DEV void tile16_step_f32(const TileQ& c, const LaneConst<float>& lc, float&
         "v_mov_b32_dpp %[si1], %[a] " ILQR_QB1 DPPT                   //  a  SK[i][1]
         "v_mov_b32_dpp %[si2], %[a] " ILQR_QB2 DPPT                   //  b  SK[i][2]
         "v_mov_b32_dpp %[si3], %[a] " ILQR_QB3 DPPT                   //  c  SK[i][3]
-        "v_mov_b32_dpp %[Quxi], %[c] " ILQR_QB2 DPPT                  //  d  Q_ux[i] (row form) = l_ux[i] + ...
         "v_mul_f32_dpp %[P], %[a], %[V] " ILQR_QB0 DPPT               //  1 A   SK[i][0] * V
         "v_mul_f32_dpp %[pu], %[c], %[V] " ILQR_QB0 DPPT              //  2 B   f_u[i] * V
-        "v_mul_f32 %[pr], %[vj0], %[V]\n\t"                         //  3 R   f_u[j] * V[i][j]
         "v_fma_f32 %[qx], %[sj0], %[vx], %[vj1]\n\t"                //  4 C   Q_x = l_x + ...
         "v_fmac_f32_dpp %[P], %[V], %[si1] row_ror:12" DPPT           //  5 A
-        "v_add_f32_dpp %[t], %[pu], %[pu] row_ror:8" DPPT             //  6 B   pu[i] + pu[i+2]
-        "v_add_f32_dpp %[t2], %[pr], %[pr] " ILQR_QSW DPPE            //  7 R
-        : [P] "=&v"(P), [pu] "=&v"(pu), [pr] "=&v"(pr), [qx] "=&v"(qx), [t] "=&v"(t), [t2] "=&v"(t2), [si1] "=&v"(si1),
-          [si2] "=&v"(si2), [si3] "=&v"(si3), [Quxi] "=&v"(Quxi)
-        : [V] "v"(V), [vx] "v"(vx), [a] "v"(c.a), [c] "v"(c.c), [sj0] "v"(c.skj[0]), [vj0] "v"(c.vj[0]), [vj1] "v"(c.vj[1]));
+        "v_add_f32_dpp %[t], %[pu], %[pu] row_ror:8" DPPE             //  6 B   pu[i] + pu[i+2]
+        : [P] "=&v"(P), [pu] "=&v"(pu), [qx] "=&v"(qx), [t] "=&v"(t), [si1] "=&v"(si1), [si2] "=&v"(si2), [si3] "=&v"(si3)
+        : [V] "v"(V), [vx] "v"(vx), [a] "v"(c.a), [c] "v"(c.c), [sj0] "v"(c.skj[0]), [vj1] "v"(c.vj[1]));
     if constexpr (REFILL) prev.template issue_part<0>(srd, off, soff);
     asm volatile(
         "v_fmac_f32_dpp %[qx], %[vx], %[sj1] " ILQR_QP1 DPPT          //  8 C
         "v_fmac_f32_dpp %[P], %[V], %[si2] row_ror:8" DPPT            //  9 A
         "v_add_f32_dpp %[pu], %[t], %[t] row_ror:12" DPPT             // 10 B   pu done (down the rows; column form)
-        "v_add_f32_dpp %[pr], %[t2], %[t2] " ILQR_QP2 DPPT            // 11 R   pr done (along the row; row form)
         "v_mul_f32 %[qu], %[vj0], %[vx]\n\t"                        // 12 C2  f_u[j] * V_x[j]
         "v_fmac_f32_dpp %[qx], %[vx], %[sj2] " ILQR_QP2 DPPT          // 13 C
         "v_fmac_f32_dpp %[P], %[V], %[si3] row_ror:4" DPPE            // 14 A   P done
-        : [qx] "+v"(qx), [P] "+v"(P), [qu] "=&v"(qu), [pu] "=&v"(pu), [pr] "=&v"(pr)
+        : [qx] "+v"(qx), [P] "+v"(P), [qu] "=&v"(qu), [pu] "=&v"(pu)
         : [V] "v"(V), [vx] "v"(vx), [si2] "v"(si2), [si3] "v"(si3), [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]),
-          [vj0] "v"(c.vj[0]), [t] "v"(t), [t2] "v"(t2));
+          [vj0] "v"(c.vj[0]), [t] "v"(t));
     if constexpr (REFILL) prev.template issue_part<1>(srd, off, soff);
     asm volatile(
         "v_mul_f32 %[quu], %[pu], %[vj0]\n\t"                       // 15 Q   pu[j] * f_u[j]
         "v_fma_f32 %[Qux], %[sj0], %[pu], %[vj2]\n\t"               // 16 B   Q_ux[j] = l_ux[j] + ...
-        "v_fmac_f32_dpp %[Quxi], %[a], %[pr] " ILQR_QB0 DPPT          // 17 R   Q_ux[i] += SK[i][0] * pr
         "v_fmac_f32_dpp %[qx], %[vx], %[sj3] " ILQR_QP3 DPPT          // 18 C   Q_x done
         "v_fmac_f32 %[quu], %[m1], %[vj3]\n\t"                      // 19 Q   + l_uu on lane j = 1
         "v_fmac_f32 %[qu], %[m0], %[vj3]\n\t"                       // 20 C2  + l_u on lane j = 0
         "v_fma_f32 %[Qxx], %[sj0], %[P], %[lxx]"                      // 21 A   Q_xx = l_xx + ...
-        : [quu] "=&v"(quu), [Qux] "=&v"(Qux), [Quxi] "+v"(Quxi), [Qxx] "=&v"(Qxx), [qx] "+v"(qx), [qu] "+v"(qu)
-        : [vx] "v"(vx), [a] "v"(c.a), [sj0] "v"(c.skj[0]), [sj3] "v"(c.skj[3]), [vj0] "v"(c.vj[0]), [vj2] "v"(c.vj[2]),
-          [vj3] "v"(c.vj[3]), [lxx] "v"(c.lxx), [m0] "v"(lc.m0), [m1] "v"(lc.m1), [pu] "v"(pu), [pr] "v"(pr), [P] "v"(P));
+        : [quu] "=&v"(quu), [Qux] "=&v"(Qux), [Qxx] "=&v"(Qxx), [qx] "+v"(qx), [qu] "+v"(qu)
+        : [vx] "v"(vx), [sj0] "v"(c.skj[0]), [sj3] "v"(c.skj[3]), [vj0] "v"(c.vj[0]), [vj2] "v"(c.vj[2]),
+          [vj3] "v"(c.vj[3]), [lxx] "v"(c.lxx), [m0] "v"(lc.m0), [m1] "v"(lc.m1), [pu] "v"(pu), [P] "v"(P));
     if constexpr (REFILL) prev.template issue_part<2>(srd, off, soff);
     asm volatile(
         "v_fmac_f32_dpp %[Qux], %[pu], %[sj1] " ILQR_QP1 DPPT         // 22 B
         "v_add_f32_dpp %[t2], %[quu], %[quu] " ILQR_QSW DPPT          // 23 Q
-        "v_fmac_f32_dpp %[Quxi], %[pr], %[si1] row_ror:12" DPPT       // 24 R
         "v_add_f32_dpp %[t], %[qu], %[qu] " ILQR_QSW DPPT             // 25 C2
         "v_fmac_f32_dpp %[Qxx], %[P], %[sj1] " ILQR_QP1 DPPT          // 26 A
         "v_add_f32_dpp %[quu], %[t2], %[t2] " ILQR_QP2 DPPT           // 27 Q   Q_uu done
         "v_fmac_f32_dpp %[Qux], %[pu], %[sj2] " ILQR_QP2 DPPE         // 28 B
-        : [Qux] "+v"(Qux), [Quxi] "+v"(Quxi), [Qxx] "+v"(Qxx), [quu] "+v"(quu), [t] "=&v"(t), [t2] "=&v"(t2)
-        : [si1] "v"(si1), [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]), [pu] "v"(pu), [pr] "v"(pr), [P] "v"(P), [qu] "v"(qu));
+        : [Qux] "+v"(Qux), [Qxx] "+v"(Qxx), [quu] "+v"(quu), [t] "=&v"(t), [t2] "=&v"(t2)
+        : [sj1] "v"(c.skj[1]), [sj2] "v"(c.skj[2]), [pu] "v"(pu), [P] "v"(P), [qu] "v"(qu));
     if constexpr (REFILL) prev.template issue_part<3>(srd, off, soff);
     asm volatile(
-        "v_fmac_f32_dpp %[Quxi], %[pr], %[si2] row_ror:8" DPPT        // 29 R
         "v_add_f32_dpp %[qu], %[t], %[t] " ILQR_QP2 DPPT              // 30 C2  Q_u done
         "v_rcp_f32 %[inv], %[quu]\n\t"                              // 31 Q   r ~ 1 / Q_uu
         "v_fmac_f32_dpp %[Qxx], %[P], %[sj2] " ILQR_QP2 DPPT          // 32 A
         "v_fmac_f32_dpp %[Qux], %[pu], %[sj3] " ILQR_QP3 DPPT         // 33 B   Q_ux (column form) done
         "v_fma_f32 %[e], -%[quu], %[inv], 1.0\n\t"                  // 34 Q   e = 1 - Q_uu r
-        "v_fmac_f32_dpp %[Quxi], %[pr], %[si3] row_ror:4" DPPT        // 35 R   Q_ux (row form) done
         "v_fmac_f32_dpp %[Qxx], %[P], %[sj3] " ILQR_QP3 DPPT          // 36 A   Q_xx done
-        "v_fmac_f32 %[inv], %[e], %[inv]"                             // 37 Q   r += e r (one Newton step)
-        : [Quxi] "+v"(Quxi), [Qxx] "+v"(Qxx), [Qux] "+v"(Qux), [qu] "=&v"(qu), [inv] "=&v"(inv), [e] "=&v"(t2)
-        : [si2] "v"(si2), [si3] "v"(si3), [sj2] "v"(c.skj[2]), [sj3] "v"(c.skj[3]), [pu] "v"(pu), [pr] "v"(pr),
-          [P] "v"(P), [t] "v"(t), [quu] "v"(quu));
+        // R: Q_ux in ROW form (lane (i, j) <- Q_ux[i]) = lane i of quad i of the column form, broadcast inside each quad by
+        // four masked moves (bank_mask: one quad of every row per move); they sit where the tail used to wait for 1/Q_uu
+        "v_mov_b32_dpp %[Quxi], %[Qux] " ILQR_QB0 " row_mask:0xf bank_mask:0x1\n\t"
+        "v_fmac_f32 %[inv], %[e], %[inv]\n\t"                         // 37 Q   r += e r (one Newton step)
+        "v_mov_b32_dpp %[Quxi], %[Qux] " ILQR_QB1 " row_mask:0xf bank_mask:0x2\n\t"
+        "v_mov_b32_dpp %[Quxi], %[Qux] " ILQR_QB2 " row_mask:0xf bank_mask:0x4\n\t"
+        "v_mov_b32_dpp %[Quxi], %[Qux] " ILQR_QB3 " row_mask:0xf bank_mask:0x8"
+        : [Quxi] "=&v"(Quxi), [Qxx] "+v"(Qxx), [Qux] "+v"(Qux), [qu] "=&v"(qu), [inv] "=&v"(inv), [e] "=&v"(t2)
+        : [sj2] "v"(c.skj[2]), [sj3] "v"(c.skj[3]), [pu] "v"(pu), [P] "v"(P), [t] "v"(t), [quu] "v"(quu));
     if constexpr (REFILL) prev.template issue_part<4>(srd, off, soff);
 #undef DPPT
 #undef DPPE
