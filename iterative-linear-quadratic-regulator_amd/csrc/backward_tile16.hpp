@@ -468,8 +468,14 @@ ILQR_DEV void tile16_step(const Tile16<T>& c, const LaneConst<T>& lc, T mu, T& V
     const T inv = fast_rcp(Qr);
     Kj = -(Qux * inv);   // K = -Q_uu^-1 Q_ux   (:109)
     kff = -(Qu * inv);   // k = -Q_uu^-1 Q_u    (:110)
-    // Q_ux in "row form": lane (i, j) <- Q_ux[i], held by lane (j, i)
-    const T Quxi = lane_transpose(Qux, lc.tr_byte);
+    // Q_ux in "row form": lane (i, j) <- Q_ux[i] = the column form's lane i of quad i, broadcast inside each quad by four
+    // masked DPP moves (bank_mask: one quad of every 16-lane row per move).  Until round 3 a ds_bpermute from lane (j, i)
+    // -- the 4 x 4 transpose through the LDS crossbar -- whose ~68 cycles sat on the step's serial path.
+    T Quxi = Qux;
+    Quxi = dpp_row<dpp_quad(0, 0, 0, 0), 0x1>(Quxi, Qux);
+    Quxi = dpp_row<dpp_quad(1, 1, 1, 1), 0x2>(Quxi, Qux);
+    Quxi = dpp_row<dpp_quad(2, 2, 2, 2), 0x4>(Quxi, Qux);
+    Quxi = dpp_row<dpp_quad(3, 3, 3, 3), 0x8>(Quxi, Qux);
     // Q_xx = l_xx + P f_x
     const T Qxx = contract_row(c.skj, P, c.lxx);
     if constexpr (!REG) {
