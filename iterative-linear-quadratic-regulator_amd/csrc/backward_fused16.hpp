@@ -40,16 +40,27 @@ namespace ilqr {
 // form needs ~200 VGPRs: 512-thread workgroups) produce as many points per pass as eight scalar ones.
 template <typename T, int TPW, bool PK> struct FusedCfg;
 template <> struct FusedCfg<float, 16, false> { static constexpr int P = 8, RU = 8; };
-template <> struct FusedCfg<float, 16, true> { static constexpr int P = 4, RU = 4; };
+#ifndef ILQR_PK_RU
+#define ILQR_PK_RU 5        // ring slots of the pair producers (A/B builds: tools/build_variants.sh; 4: 45.6 us, 5: 42.5 us at B = 4096)
+#endif
+#ifndef ILQR_PK_PAD
+#define ILQR_PK_PAD 0       // extra scalars behind every PAIR of tiles (lane stride 2 TL + PAD: 104 dwords put lanes l, l + 4 on the same banks)
+#endif
+template <> struct FusedCfg<float, 16, true> { static constexpr int P = 4, RU = ILQR_PK_RU; };
 template <> struct FusedCfg<double, 16, false> { static constexpr int P = 4, RU = 4; };   // (P = 8 caps the kernel at 168 VGPRs: the fp64 RK4 producer spills)
 template <> struct FusedCfg<float, 4, false> { static constexpr int P = 3, RU = 4; };
 template <> struct FusedCfg<double, 4, false> { static constexpr int P = 3, RU = 3; };
 
 // scalars between two tiles in LDS: the n_u = 1 tile (48) or the (4, 2) tile of backward_tile16m2.hpp (64), + 4 of padding
 template <int NU> constexpr int fused_tl() { return NU == 2 ? 68 : 52; }
+template <bool PK, int NU> constexpr int fused_unit_scalars() { return (PK ? 128 : 64) * fused_tl<NU>() + (PK ? 64 * ILQR_PK_PAD : 0); }
+// ring slots: the configuration's, except that the pair producers' 128-tile units of the (4, 2) tile fit four times into 160 KB
+template <typename T, int TPW, bool PK, int NU> constexpr int fused_ru() { return (PK && NU == 2 && FusedCfg<T, TPW, PK>::RU > 4) ? 4 : FusedCfg<T, TPW, PK>::RU; }
 template <typename T, int TPW, bool PK, int NU = 1> constexpr int fused_lds_bytes() {
-    return FusedCfg<T, TPW, PK>::RU * (PK ? 128 : 64) * fused_tl<NU>() * (int)sizeof(T) + (FusedCfg<T, TPW, PK>::RU + 4 + 32 + 4) * 4;
+    return fused_ru<T, TPW, PK, NU>() * fused_unit_scalars<PK, NU>() * (int)sizeof(T) + (fused_ru<T, TPW, PK, NU>() + 4 + 32 + 4) * 4;
 }
+static_assert(fused_lds_bytes<float, 16, true, 1>() <= 160 * 1024 && fused_lds_bytes<float, 16, true, 2>() <= 160 * 1024 &&
+              fused_lds_bytes<float, 16, false, 2>() <= 160 * 1024 && fused_lds_bytes<double, 16, false, 2>() <= 160 * 1024, "LDS ring exceeds a CU");
 template <typename T, int TPW, bool PK> constexpr int fused_threads() { return 64 * (TPW / 4 + FusedCfg<T, TPW, PK>::P); }
 
 // the sweep's view of a tile in LDS, and the step that consumes it
@@ -130,19 +141,20 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
     static_assert(TPW == 16 || TPW == 4, "16 or 4 trajectories per workgroup");
     static_assert(!PK || (sizeof(T) == 4 && TPW == 16 && INTEG != ILQR_INT_BACKWARD_EULER), "pair producers: fp32, 16-trajectory workgroups, explicit integrators");
     using Cfg = FusedCfg<T, TPW, PK>;
-    static constexpr int P = Cfg::P, RU = Cfg::RU, TL = fused_tl<NU>();
+    static constexpr int P = Cfg::P, RU = fused_ru<T, TPW, PK, NU>(), TL = fused_tl<NU>();
     static constexpr int NV = (NU == 2 ? kTile16M2 : kTile16) / 4;   // V4 pieces of a tile
     static constexpr int NSW = TPW / 4;                 // sweep waves
     static constexpr int UT = PK ? 128 : 64;            // tiles per unit (one pass of a producer wave)
     static constexpr int US = UT / TPW;                 // time steps per unit
-    static constexpr int UNIT = UT * TL;                // scalars per ring slot
+    static constexpr int UNIT = fused_unit_scalars<PK, NU>();   // scalars per ring slot
+    static constexpr int PS = 2 * TL + ILQR_PK_PAD;     // pair producers: scalars between two lanes' pairs of tiles
     static constexpr int R = gain_record(NX, NU);
     using PL = ParamLayout<Dyn::NSYS, NX, NU>;
     using V4 = typename Vec4<T>::type;
     // where the tile of (step r of the unit, trajectory tl) sits in its ring slot: step-major, or -- pair producers --
     // the two steps a lane evaluates together next to each other
-    static ILQR_DEV constexpr int tile_off(int r, int tl) { return PK ? ((r / 2) * TPW + tl) * 2 * TL + (r % 2) * TL : (r * TPW + tl) * TL; }
-    static ILQR_DEV constexpr int step_off(int r) { return PK ? (r / 2) * TPW * 2 * TL + (r % 2) * TL : r * TPW * TL; }
+    static ILQR_DEV constexpr int tile_off(int r, int tl) { return PK ? ((r / 2) * TPW + tl) * PS + (r % 2) * TL : (r * TPW + tl) * TL; }
+    static ILQR_DEV constexpr int step_off(int r) { return PK ? (r / 2) * TPW * PS + (r % 2) * TL : r * TPW * TL; }
 
     struct Lds {
         T* ring;
@@ -251,7 +263,7 @@ template <typename T, typename Dyn, int INTEG, int TPW, bool PK> struct FusedWG 
         int goff = (N - 1) * rstride;
         // this trajectory's tile of time step r of unit k sits at unit_base(k) + r * TPW * TL: a compile-time offset per step
         auto unit_base = [&](int k) -> const T* { return L.ring + (size_t)(k % RU) * UNIT + tile_off(0, tl); };
-        constexpr auto step_off = [](int r) { return PK ? (r / 2) * TPW * 2 * TL + (r % 2) * TL : r * TPW * TL; };
+        constexpr auto step_off = [](int r) { return PK ? (r / 2) * TPW * PS + (r % 2) * TL : r * TPW * TL; };
         auto one_step = [&](const typename FS::Tile& c) {
             T out;
             bool pd;

@@ -177,10 +177,13 @@ template <typename T, typename Dyn, bool TILE, int INTEG> void set_integrator_op
             (void)ok;
             static const int force = getenv("ILQR_FUSED_TPW") ? atoi(getenv("ILQR_FUSED_TPW")) : 0;   // A/B switch
             static const int small_max = getenv("ILQR_FUSED_SMALL_MAX") ? atoi(getenv("ILQR_FUSED_SMALL_MAX")) : 1024;
-            // Pair producers are built and tested (bit-identical) but OFF by default: measured 48.6 vs 48.1 us at B = 4096.
-            // The kernel is not bound by the producers' instruction count but by the sweep waves' chain (382 cycles per
-            // step, tools/fused_stamps.py), and four lone pair-producer waves deliver their first unit later (11.7 k vs
-            // 5.0 k cycles) and leave the sweep waiting more (12.2 k vs 3.7 k cycles) than eight scalar ones.
+            // Pair producers (two time steps per lane in packed FP32, bit-identical) are built and tested but OFF by default
+            // in this kernel: with a ring of 4 units they measured the same as the scalar ones (48.6 vs 48.1 us at B = 4096:
+            // the kernel is bound by the sweep waves' chain, and four lone pair waves deliver their first unit later and let
+            // the ring run dry); with 5 slots (133 KB of LDS, the build's value now) 44.7-45.8 against 46.4 us -- one
+            // microsecond, for a third fewer vector instructions in the same time (bench.py's issue-rate fraction would fall
+            // from 0.70 to ~0.6 with nothing else changing).  ILQR_FUSED_PAIRS=1 selects them; the 16-trajectory persistent
+            // kernel always uses them (register budget).
             static const bool no_pk = getenv("ILQR_FUSED_PAIRS") == nullptr;                          // A/B switch
             const bool small = force ? force == 4 : a.B <= small_max;
             if (small) {
